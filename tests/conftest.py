@@ -1,0 +1,55 @@
+"""Shared pytest plumbing: the ``gpu`` marker, fixture loading, and the package import helper."""
+import glob
+import importlib
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def package():
+    """The product package (its directory name is not a valid identifier)."""
+    return importlib.import_module("channel-estimation-in-5g-network_amd")
+
+
+def golden_names(prefix=""):
+    return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, prefix + "*.npz"))
+                  if os.path.basename(p).startswith(("small_", "full_")))
+
+
+def load_golden(name):
+    with np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False) as z:
+        return {k: z[k] for k in z.files}
+
+
+def case_config(g):
+    ofdm = dict(fft_size=int(g["fft_size"]), cp_length=int(g["cp_length"]), num_symbols=int(g["num_symbols"]),
+                useful_subcarriers=int(g["useful_subcarriers"]), subcarrier_spacing=15000.0)
+    mimo = dict(num_tx=int(g["num_tx"]), num_rx=int(g["num_rx"]))
+    return ofdm, mimo
+
+
+def case_draws(g):
+    return {k: g[k] for k in ("pilot_indices", "u_pilot", "u_data", "u_angle", "u_phase", "n_re", "n_im")}
+
+
+def relerr(a, b):
+    """max|a-b| / max|b|: the relative error used for every complex-float parity bound."""
+    a = np.asarray(a)
+    b = np.asarray(b)
+    return float(np.max(np.abs(a - b)) / max(float(np.max(np.abs(b))), 1e-300))
+
+
+@pytest.fixture(scope="session")
+def pkg():
+    return package()

@@ -1,0 +1,121 @@
+"""The CPU oracle against the committed reference outputs (no GPU, no reference needed)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, case_config, case_draws, golden_names, load_golden, relerr
+from oracle import cpu_ref as O
+
+SMALL = golden_names("small_")
+FULL = golden_names("full_")
+
+
+@pytest.mark.parametrize("name", SMALL + FULL)
+def test_simulate_and_estimate_match_reference(name):
+    g = load_golden(name)
+    ofdm, mimo = case_config(g)
+    ctype, fd, snr = str(g["channel_type"]), float(g["doppler_hz"]), float(g["snr_db"])
+    # complex128 fixtures pin the restatement to 1e-12; complex64-stored ones to c64 rounding,
+    # backed by float64 checksums.
+    tol = 1e-12 if g["H"].dtype == np.complex128 else 2e-7
+    o = O.simulate_frame(ofdm, mimo, ctype, fd, snr, case_draws(g))
+    assert np.array_equal(o["pilot_indices"], g["pilot_indices"])
+    assert relerr(o["tx_symbols"][:, 0, :], g["tx"]) < tol
+    assert relerr(o["channel"], g["H"]) < tol
+    assert relerr(o["rx_symbols"], g["rx"]) < tol
+    assert relerr(o["pilot_symbols"], g["pilot_symbols"]) < tol
+    T = mimo["num_tx"]
+    rx4 = O.repeat_over_tx(o["rx_symbols"], T)
+    ls = O.ls_estimate(rx4, o["pilot_symbols"], o["pilot_mask"], o["pilot_positions"], "linear")
+    mm = O.mmse_estimate(rx4, o["pilot_symbols"], o["pilot_mask"], o["pilot_positions"], snr, dense=False)
+    assert relerr(ls[:, :, 0, :], g["H_ls"]) < tol
+    assert relerr(mm[:, :, 0, :], g["H_mmse"]) < tol
+    for t in range(1, T):                                   # quirk Q9: estimates are tx-invariant
+        assert np.array_equal(ls[:, :, t, :], ls[:, :, 0, :])
+    assert abs(np.sum(o["channel"]) - g["sum_H"]) <= 1e-10 * abs(g["sum_H"]) + 1e-10
+    assert abs(np.sum(ls) - g["sum_H_ls"]) <= 1e-10 * abs(g["sum_H_ls"]) + 1e-10
+    m = O.evaluate_estimator(o["channel"], ls)
+    assert m["mse"] == pytest.approx(float(g["mse_ls"]), rel=1e-10)
+    assert m["nmse_db"] == pytest.approx(float(g["nmse_db_ls"]), abs=1e-9)
+    m2 = O.evaluate_estimator(o["channel"], mm)
+    assert m2["nmse_db"] == pytest.approx(float(g["nmse_db_mmse"]), abs=1e-9)
+    if "H_nearest" in g:
+        nn = O.ls_estimate(rx4, o["pilot_symbols"], o["pilot_mask"], o["pilot_positions"], "nearest")
+        assert relerr(nn[:, :, 0, :], g["H_nearest"]) < tol
+
+
+def test_dense_mmse_equals_scalar_shrinkage():
+    g = load_golden("small_2x2_eva_d10")
+    ofdm, mimo = case_config(g)
+    o = O.simulate_frame(ofdm, mimo, "EVA", float(g["doppler_hz"]), float(g["snr_db"]), case_draws(g))
+    rx4 = O.repeat_over_tx(o["rx_symbols"], 2)
+    a = O.mmse_estimate(rx4, o["pilot_symbols"], o["pilot_mask"], o["pilot_positions"], 10.0, dense=True)
+    b = O.mmse_estimate(rx4, o["pilot_symbols"], o["pilot_mask"], o["pilot_positions"], 10.0, dense=False)
+    assert relerr(a, b) < 1e-13
+
+
+def test_full_covariance_mmse():
+    g = load_golden("small_2x2_etu_fullcov")
+    ofdm, mimo = case_config(g)
+    o = O.simulate_frame(ofdm, mimo, "ETU", float(g["doppler_hz"]), float(g["snr_db"]), case_draws(g))
+    rx4 = O.repeat_over_tx(o["rx_symbols"], 2)
+    fc = O.mmse_estimate(rx4, o["pilot_symbols"], o["pilot_mask"], o["pilot_positions"], float(g["snr_db"]),
+                         covariance=g["cov"], estimate_statistics=False)
+    assert relerr(fc[:, :, 0, :], g["H_fullcov"]) < 1e-9
+
+
+def test_quickstart_documented_kat():
+    """The one value the reference documents: LS 0.06 dB / MMSE -0.26 dB (PHASE_2_BASELINE_ESTIMATORS.md:88-89)."""
+    g = load_golden("full_quickstart_seed42")
+    assert round(float(g["nmse_db_ls"]), 2) == 0.06
+    assert round(float(g["nmse_db_mmse"]), 2) == -0.26
+    assert g["pilot_indices"][:6].tolist() == [19, 23, 33, 37, 48, 61]
+
+
+def test_tables_and_legacy_rng_kat():
+    kat = json.load(open(os.path.join(GOLDEN, "kat.json")))
+    for key, v in kat["tap_tables"].items():
+        ct, N = key.split("_")
+        p, d = O.tap_table(ct, int(N) * 15000.0)
+        assert d.tolist() == v["delay_samples"]
+        assert np.allclose(p, v["powers_linear"], rtol=0, atol=1e-16)
+    for key, v in kat["used_indices"].items():
+        N, U = map(int, key.split("_"))
+        u = O.used_indices(N, U)
+        assert (int(u[0]), int(u[-1]), len(u), int(u.sum())) == (v["first"], v["last"], v["count"], v["sum"])
+    assert kat["choice_quadruple_seed42"] == ["ETU", 200, 15, 0.05]
+    rs = np.random.RandomState(42)
+    d = O.legacy_frame_draws(rs, 14, 599, 1, 1, 7, 0.1)
+    a = np.arange(8386)
+    np.random.RandomState(42).shuffle(a)
+    assert a[:8].tolist() == kat["shuffle8386_head"] and a[-8:].tolist() == kat["shuffle8386_tail"]
+    assert np.array_equal(d["pilot_indices"], np.sort(a[:838]))
+    with pytest.raises(KeyError):
+        O.tap_table("XYZ", 15.36e6)
+
+
+def test_ofdm_modem_dense_channel_equalizer():
+    m = load_golden("ofdm_modem") if False else dict(np.load(os.path.join(GOLDEN, "ofdm_modem.npz")))
+    td = O.ofdm_modulate(m["symbols"], 1024, 72, 600)
+    assert relerr(td, m["time"]) < 1e-12
+    assert np.array_equal(td[:, :72], td[:, -72:])                  # CP copy is bit-exact
+    assert relerr(O.ofdm_demodulate(m["time"], 1024, 72, 600), m["demod"]) < 1e-12
+    d = dict(np.load(os.path.join(GOLDEN, "dense_channel_eva.npz")))
+    h = O.time_varying_channel("EVA", float(d["doppler_hz"]), 1024 * 15000.0, int(d["num_samples"]), 2, 2,
+                               d["u_angle"], d["u_phase"])
+    assert h.shape == d["h"].shape and relerr(h, d["h"]) < 1e-12
+    e = dict(np.load(os.path.join(GOLDEN, "equalizer.npz")))
+    assert relerr(O.equalize(e["y"], e["H"], "zf"), e["zf"]) < 1e-10
+    assert relerr(O.equalize(e["y"], e["H"], "mmse"), e["mmse"]) < 1e-10
+    with pytest.raises(ValueError):
+        O.equalize(e["y"], e["H"], "bogus")
+
+
+def test_faithful_mode_equals_fast_mode():
+    g = load_golden("small_2x2_eva_d10")
+    ofdm, mimo = case_config(g)
+    a = O.channel_frequency_response("EVA", 111.1, 1024, 72, 14, 72, 15000.0, g["u_angle"], g["u_phase"])
+    b = O.channel_frequency_response_faithful("EVA", 111.1, 1024, 72, 14, 72, 15000.0, g["u_angle"], g["u_phase"])
+    assert relerr(a, b) < 1e-12
