@@ -1,0 +1,320 @@
+// Host side of the C ABI declared in include/chest.h: context, tap tables, pattern storage,
+// argument checking, and the thin extern "C" wrappers around the kernel launchers.
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <new>
+
+#include "chest_internal.h"
+
+namespace chest {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+// 3GPP TS 36.101 Annex B.2 delay profiles as the reference tabulates them
+// (src/channel_simulator.py:41-54): delays in ns, relative powers in dB.
+struct ProfileTable { int n; double delay_ns[9]; double power_db[9]; };
+static const ProfileTable kProfiles[CHEST_NUM_PROFILES] = {
+    {7, {0, 30, 70, 90, 110, 190, 410}, {0.0, -1.0, -2.0, -3.0, -8.0, -17.2, -20.8}},
+    {9, {0, 30, 150, 310, 370, 710, 1090, 1730, 2510}, {0.0, -1.5, -1.4, -3.6, -0.6, -9.1, -7.0, -12.0, -16.9}},
+    {9, {0, 50, 120, 200, 230, 500, 1600, 2300, 5000}, {-1.0, -1.0, -1.0, 0.0, 0.0, 0.0, -3.0, -5.0, -7.0}},
+};
+
+static int build_tables(chest_ctx* ctx) {
+    const chest_config& c = ctx->cfg;
+    FrameParams& fp = ctx->fp;
+    memset(&fp, 0, sizeof(fp));
+    fp.N = c.fft_size; fp.cp = c.cp_length; fp.S = c.num_symbols; fp.U = c.useful_subcarriers;
+    fp.half = c.useful_subcarriers / 2;
+    // used = arange(dc - U//2, dc + U//2) minus dc  (src/channel_simulator.py:141-148)
+    fp.nsc = 2 * fp.half - 1;
+    fp.T = c.num_tx; fp.R = c.num_rx; fp.G = fp.S * fp.nsc;
+    const double fs = (double)c.fft_size * c.subcarrier_spacing;          // (:136, :379)
+    for (int s = 0; s < fp.S; ++s) fp.ts[s] = (float)((double)((int64_t)s * (c.fft_size + c.cp_length)) / fs);
+    for (int ty = 0; ty < CHEST_NUM_PROFILES; ++ty) {
+        const ProfileTable& pt = kProfiles[ty];
+        double lin[CHEST_MAX_PATHS], tot = 0.0;
+        for (int l = 0; l < pt.n; ++l) { lin[l] = pow(10.0, pt.power_db[l] / 10.0); tot += lin[l]; }   // (:75)
+        ctx->num_paths[ty] = pt.n;
+        for (int l = 0; l < pt.n; ++l) {
+            ctx->powers_linear[ty][l] = lin[l] / tot;                                                 // (:78)
+            // np.round(delays * fs).astype(int): round-half-even on float64 (:81)
+            ctx->delay_samples[ty][l] = (int32_t)nearbyint((pt.delay_ns[l] * 1e-9) * fs);
+        }
+        TapProfile& tp = fp.prof[ty];
+        tp.ntaps = 0; tp.npaths = pt.n; tp.max_delay = 0;
+        for (int l = 0; l < pt.n; ++l) {
+            // later path with the same delay overwrites the earlier one (:125, quirk Q1)
+            bool overwritten = false;
+            for (int m = l + 1; m < pt.n; ++m)
+                if (ctx->delay_samples[ty][m] == ctx->delay_samples[ty][l]) overwritten = true;
+            if (ctx->delay_samples[ty][l] > tp.max_delay) tp.max_delay = ctx->delay_samples[ty][l];
+            if (overwritten) continue;
+            if (tp.ntaps >= KT) { set_error("profile %d has more than %d distinct delays", ty, KT); return CHEST_EINVAL; }
+            tp.delay[tp.ntaps] = ctx->delay_samples[ty][l];
+            tp.path[tp.ntaps] = l;
+            tp.amp[tp.ntaps] = (float)(sqrt(ctx->powers_linear[ty][l]) / sqrt(2.0 * CHEST_NUM_OSC));   // (:104, :124)
+            ++tp.ntaps;
+        }
+    }
+    const int iters = (fp.nsc + 1023) / 1024;
+    const int per = (fp.nsc + iters - 1) / iters;
+    ctx->block_threads = ((per + 63) / 64) * 64;
+    return CHEST_OK;
+}
+
+static int upload_pattern_table_entry(chest_ctx* ctx, int slot) {
+    if (slot >= ctx->pattern_cap) {
+        int cap = ctx->pattern_cap ? ctx->pattern_cap : 16;
+        while (cap <= slot) cap *= 2;
+        PatternDev* nd = nullptr;
+        CHEST_HIP(hipMalloc((void**)&nd, (size_t)cap * sizeof(PatternDev)));
+        CHEST_HIP(hipMemset(nd, 0, (size_t)cap * sizeof(PatternDev)));
+        std::vector<PatternDev> host(ctx->patterns.size());
+        for (size_t i = 0; i < host.size(); ++i) host[i] = ctx->patterns[i].dev;
+        if (!host.empty()) CHEST_HIP(hipMemcpy(nd, host.data(), host.size() * sizeof(PatternDev), hipMemcpyHostToDevice));
+        CHEST_HIP(hipDeviceSynchronize());
+        if (ctx->d_patterns) CHEST_HIP(hipFree(ctx->d_patterns));
+        ctx->d_patterns = nd;
+        ctx->pattern_cap = cap;
+    }
+    CHEST_HIP(hipMemcpy(ctx->d_patterns + slot, &ctx->patterns[slot].dev, sizeof(PatternDev), hipMemcpyHostToDevice));
+    return CHEST_OK;
+}
+
+}  // namespace chest
+
+using namespace chest;
+
+extern "C" {
+
+const char* chest_last_error(void) { return g_err; }
+int chest_abi_version(void) { return CHEST_ABI_VERSION; }
+
+int chest_create(const chest_config* cfg, chest_ctx** out) {
+    if (cfg == nullptr || out == nullptr) { set_error("chest_create: null argument"); return CHEST_EINVAL; }
+    *out = nullptr;
+    if (cfg->fft_size < 8 || cfg->fft_size > 8192 || cfg->cp_length < 0 || cfg->num_symbols < 1 ||
+        cfg->num_symbols > CHEST_MAX_SYMBOLS || cfg->useful_subcarriers < 4 ||
+        cfg->useful_subcarriers > cfg->fft_size || cfg->num_tx < 1 || cfg->num_tx > 8 || cfg->num_rx < 1 ||
+        cfg->num_rx > 8 || !(cfg->subcarrier_spacing > 0)) {
+        set_error("chest_create: unsupported configuration (fft %d cp %d S %d U %d T %d R %d)", cfg->fft_size,
+                  cfg->cp_length, cfg->num_symbols, cfg->useful_subcarriers, cfg->num_tx, cfg->num_rx);
+        return CHEST_EINVAL;
+    }
+    if ((int64_t)cfg->num_symbols * (2 * (cfg->useful_subcarriers / 2) - 1) > 65535) {
+        set_error("chest_create: S*nsc must be <= 65535 (16-bit resource-element slots)");
+        return CHEST_EINVAL;
+    }
+    int ndev = 0;
+    CHEST_HIP(hipGetDeviceCount(&ndev));
+    if (cfg->device < 0 || cfg->device >= ndev) { set_error("chest_create: device %d of %d", cfg->device, ndev); return CHEST_EINVAL; }
+    CHEST_HIP(hipSetDevice(cfg->device));
+    chest_ctx* ctx = new (std::nothrow) chest_ctx();
+    if (!ctx) { set_error("out of host memory"); return CHEST_ENOMEM; }
+    ctx->cfg = *cfg;
+    int rc = build_tables(ctx);
+    if (rc != CHEST_OK) { delete ctx; return rc; }
+    if (hipMalloc((void**)&ctx->d_status, sizeof(int32_t)) != hipSuccess ||
+        hipMemset(ctx->d_status, 0, sizeof(int32_t)) != hipSuccess) {
+        set_error("hipMalloc(status) failed");
+        delete ctx;
+        return CHEST_EHIP;
+    }
+    const int N = cfg->fft_size;
+    if ((N & (N - 1)) == 0) {                                    // FFT twiddles exp(-2 pi j n/N) from float64
+        std::vector<float2> tw(N);
+        for (int n = 0; n < N; ++n) {
+            const double a = -2.0 * M_PI * (double)n / (double)N;
+            tw[n] = make_float2((float)cos(a), (float)sin(a));
+        }
+        if (hipMalloc((void**)&ctx->d_twiddle, N * sizeof(float2)) != hipSuccess ||
+            hipMemcpy(ctx->d_twiddle, tw.data(), N * sizeof(float2), hipMemcpyHostToDevice) != hipSuccess) {
+            set_error("twiddle upload failed");
+            chest_destroy(ctx);
+            return CHEST_EHIP;
+        }
+    }
+    *out = ctx;
+    return CHEST_OK;
+}
+
+void chest_destroy(chest_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->cfg.device);
+    (void)hipDeviceSynchronize();
+    for (auto& p : ctx->patterns)
+        if (p.block) (void)hipFree(p.block);
+    if (ctx->d_patterns) (void)hipFree(ctx->d_patterns);
+    if (ctx->d_status) (void)hipFree(ctx->d_status);
+    if (ctx->d_twiddle) (void)hipFree(ctx->d_twiddle);
+    delete ctx;
+}
+
+int chest_get_used_indices(chest_ctx* ctx, int32_t* num_sc, int64_t* out) {
+    if (!ctx) { set_error("null context"); return CHEST_EINVAL; }
+    if (num_sc) *num_sc = ctx->fp.nsc;
+    if (out) {
+        const int dc = ctx->fp.N / 2, half = ctx->fp.half;
+        int n = 0;
+        for (int i = dc - half; i < dc + half; ++i)
+            if (i != dc) out[n++] = i;
+    }
+    return CHEST_OK;
+}
+
+int chest_get_tap_table(chest_ctx* ctx, int32_t type, int32_t* num_paths, int32_t* delay_samples, double* powers_linear) {
+    if (!ctx || (unsigned)type >= CHEST_NUM_PROFILES) { set_error("unknown channel_type %d", type); return CHEST_EINVAL; }
+    if (num_paths) *num_paths = ctx->num_paths[type];
+    for (int l = 0; l < ctx->num_paths[type]; ++l) {
+        if (delay_samples) delay_samples[l] = ctx->delay_samples[type][l];
+        if (powers_linear) powers_linear[l] = ctx->powers_linear[type][l];
+    }
+    return CHEST_OK;
+}
+
+int chest_pattern_set(chest_ctx* ctx, int32_t slot, const int32_t* pilot_idx, int32_t P, const uint16_t* plan_idx,
+                      const float* plan_w) {
+    if (!ctx || slot < 0 || slot > (1 << 20) || pilot_idx == nullptr) { set_error("chest_pattern_set: bad argument"); return CHEST_EINVAL; }
+    const int G = ctx->fp.G;
+    if (P < 1 || P > G) { set_error("chest_pattern_set: num_pilots %d out of range (1..%d)", P, G); return CHEST_EINVAL; }
+    if ((plan_idx == nullptr) != (plan_w == nullptr)) { set_error("plan_idx/plan_w must be given together"); return CHEST_EINVAL; }
+    for (int i = 0; i < P; ++i) {
+        if (pilot_idx[i] < 0 || pilot_idx[i] >= G || (i > 0 && pilot_idx[i] <= pilot_idx[i - 1])) {
+            set_error("chest_pattern_set: pilot_idx must be sorted, unique and inside the %d-element grid", G);
+            return CHEST_EINVAL;
+        }
+    }
+    if (plan_idx)
+        for (size_t i = 0; i < (size_t)3 * G; ++i)
+            if (plan_idx[i] >= P) { set_error("chest_pattern_set: plan index %u >= num_pilots %d", plan_idx[i], P); return CHEST_EINVAL; }
+    CHEST_HIP(hipSetDevice(ctx->cfg.device));
+    // draw slot of every resource element: i-th pilot <-> i-th True of the row-major mask
+    // (insert_pilots, src/channel_simulator.py:249-252); data symbols follow in row-major order.
+    std::vector<uint16_t> slots(G);
+    {
+        int pi = 0, di = 0;
+        for (int g = 0; g < G; ++g) {
+            if (pi < P && pilot_idx[pi] == g) slots[g] = (uint16_t)pi++;
+            else slots[g] = (uint16_t)(P + di++);
+        }
+    }
+    auto up16 = [](size_t v) { return (v + 15) & ~(size_t)15; };
+    const size_t o_slot = 0;
+    const size_t o_pidx = up16(o_slot + (size_t)G * 2);
+    const size_t o_pw = up16(o_pidx + (plan_idx ? (size_t)3 * G * 2 : 0));
+    const size_t o_pil = up16(o_pw + (plan_w ? (size_t)3 * G * 4 : 0));
+    const size_t total = up16(o_pil + (size_t)P * 4);
+    unsigned char* blk = nullptr;
+    CHEST_HIP(hipMalloc((void**)&blk, total));
+    std::vector<unsigned char> host(total, 0);
+    memcpy(host.data() + o_slot, slots.data(), (size_t)G * 2);
+    if (plan_idx) memcpy(host.data() + o_pidx, plan_idx, (size_t)3 * G * 2);
+    if (plan_w) memcpy(host.data() + o_pw, plan_w, (size_t)3 * G * 4);
+    memcpy(host.data() + o_pil, pilot_idx, (size_t)P * 4);
+    if (hipMemcpy(blk, host.data(), total, hipMemcpyHostToDevice) != hipSuccess) {
+        (void)hipFree(blk);
+        set_error("pattern upload failed");
+        return CHEST_EHIP;
+    }
+    if ((size_t)slot >= ctx->patterns.size()) ctx->patterns.resize(slot + 1);
+    PatternHost& ph = ctx->patterns[slot];
+    if (ph.block) { CHEST_HIP(hipDeviceSynchronize()); CHEST_HIP(hipFree(ph.block)); }
+    ph.block = blk;
+    ph.dev.slot = (const uint16_t*)(blk + o_slot);
+    ph.dev.plan_idx = plan_idx ? (const uint16_t*)(blk + o_pidx) : nullptr;
+    ph.dev.plan_w = plan_w ? (const float*)(blk + o_pw) : nullptr;
+    ph.dev.pilot_idx = (const int32_t*)(blk + o_pil);
+    ph.dev.P = P;
+    // table entries between the old size and `slot` stay zero (slot == nullptr -> "not set")
+    {
+        int rc = upload_pattern_table_entry(ctx, slot);
+        if (rc != CHEST_OK) return rc;
+    }
+    return CHEST_OK;
+}
+
+int chest_pattern_num_pilots(chest_ctx* ctx, int32_t slot) {
+    if (!ctx || slot < 0 || (size_t)slot >= ctx->patterns.size() || ctx->patterns[slot].block == nullptr) {
+        set_error("pattern slot %d is not set", slot);
+        return CHEST_ESTATE;
+    }
+    return ctx->patterns[slot].dev.P;
+}
+
+int chest_get_status(chest_ctx* ctx, int32_t* status) {
+    if (!ctx || !status) { set_error("null argument"); return CHEST_EINVAL; }
+    CHEST_HIP(hipSetDevice(ctx->cfg.device));
+    CHEST_HIP(hipMemcpy(status, ctx->d_status, sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (*status != 0) CHEST_HIP(hipMemset(ctx->d_status, 0, sizeof(int32_t)));
+    return CHEST_OK;
+}
+
+int chest_frames_run(chest_ctx* ctx, void* stream, int32_t B, const chest_frame_desc* descs, uint64_t seed,
+                     uint64_t frame_offset, const chest_injected* inj, const chest_frame_outputs* out) {
+    if (!ctx || !out || (B > 0 && !descs)) { set_error("chest_frames_run: null argument"); return CHEST_EINVAL; }
+    if (B < 0) { set_error("chest_frames_run: negative frame count"); return CHEST_EINVAL; }
+    if (ctx->patterns.empty()) { set_error("chest_frames_run: no pilot pattern uploaded"); return CHEST_ESTATE; }
+    if (out->pilot_symbols != nullptr) {
+        int Pmax = 0;
+        for (const auto& p : ctx->patterns) Pmax = p.dev.P > Pmax ? p.dev.P : Pmax;
+        if (out->pilot_stride < Pmax) { set_error("pilot_stride %d < largest pattern %d", out->pilot_stride, Pmax); return CHEST_EINVAL; }
+    }
+    return launch_frames(ctx, (hipStream_t)stream, B, descs, seed, frame_offset, inj, out);
+}
+
+int chest_estimate_batch(chest_ctx* ctx, void* stream, int32_t B, const float* rx4d, const float* tx_pilots,
+                         int32_t pilot_stride, int32_t slot, int32_t mmse, float snr_db, float* H_est) {
+    if (!ctx || (B > 0 && (!rx4d || !tx_pilots || !H_est))) { set_error("chest_estimate_batch: null argument"); return CHEST_EINVAL; }
+    if (B < 0 || pilot_stride < 0) { set_error("chest_estimate_batch: negative size"); return CHEST_EINVAL; }
+    return launch_estimate(ctx, (hipStream_t)stream, B, rx4d, tx_pilots, pilot_stride, slot, mmse, snr_db, H_est);
+}
+
+int chest_at_pilots(chest_ctx* ctx, void* stream, int32_t n, const float* rx, const float* tx, int32_t mmse,
+                    float snr_db, float* out) {
+    if (!ctx || n < 0 || (n > 0 && (!rx || !tx || !out))) { set_error("chest_at_pilots: bad argument"); return CHEST_EINVAL; }
+    return launch_at_pilots(ctx, (hipStream_t)stream, n, rx, tx, mmse, snr_db, out);
+}
+
+int chest_error_sums(chest_ctx* ctx, void* stream, int64_t n, const float* a, const float* b, double* out) {
+    if (!ctx || n < 0 || !out || (n > 0 && (!a || !b))) { set_error("chest_error_sums: bad argument"); return CHEST_EINVAL; }
+    return launch_error_sums(ctx, (hipStream_t)stream, n, a, b, out);
+}
+
+int chest_apply_channel(chest_ctx* ctx, void* stream, int32_t B, const float* tx, const float* H, const float* snr_db,
+                        const float* n_re, const float* n_im, uint64_t seed, uint64_t frame_offset, float* rx) {
+    if (!ctx || B < 0 || (B > 0 && (!tx || !H || !snr_db || !rx))) { set_error("chest_apply_channel: bad argument"); return CHEST_EINVAL; }
+    return launch_apply_channel(ctx, (hipStream_t)stream, B, tx, H, snr_db, n_re, n_im, seed, frame_offset, rx);
+}
+
+int chest_time_varying_channel(chest_ctx* ctx, void* stream, int32_t type, float fd, int64_t ns, int32_t T, int32_t R,
+                               const float* ua, const float* up, uint64_t seed, uint64_t frame, float* out) {
+    if (!ctx || ns < 0 || T < 0 || R < 0 || (ns > 0 && !out)) { set_error("chest_time_varying_channel: bad argument"); return CHEST_EINVAL; }
+    return launch_tv_channel(ctx, (hipStream_t)stream, type, fd, ns, T, R, ua, up, seed, frame, out);
+}
+
+int chest_ofdm_modulate(chest_ctx* ctx, void* stream, int32_t n, const float* sym, float* out) {
+    if (!ctx || n < 0 || (n > 0 && (!sym || !out))) { set_error("chest_ofdm_modulate: bad argument"); return CHEST_EINVAL; }
+    return launch_ofdm(ctx, (hipStream_t)stream, n, sym, out, true);
+}
+
+int chest_ofdm_demodulate(chest_ctx* ctx, void* stream, int32_t n, const float* tin, float* out) {
+    if (!ctx || n < 0 || (n > 0 && (!tin || !out))) { set_error("chest_ofdm_demodulate: bad argument"); return CHEST_EINVAL; }
+    return launch_ofdm(ctx, (hipStream_t)stream, n, tin, out, false);
+}
+
+int chest_equalize(chest_ctx* ctx, void* stream, int32_t B, const float* rx, const float* H, int32_t method, float* out) {
+    if (!ctx || B < 0 || (B > 0 && (!rx || !H || !out))) { set_error("chest_equalize: bad argument"); return CHEST_EINVAL; }
+    return launch_equalize(ctx, (hipStream_t)stream, B, rx, H, method, out);
+}
+
+}  // extern "C"

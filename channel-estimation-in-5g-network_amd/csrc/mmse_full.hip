@@ -1,0 +1,236 @@
+// Full-covariance MMSE: MMSEEstimator(channel_covariance=R, estimate_statistics=False)
+// (reference src/baseline_estimators.py:181-190):   h_mmse = R (R + sigma^2 I)^-1 h_ls.
+//
+// prepare: W = R (R + s2 I)^-1 = I - s2 (R + s2 I)^-1.  The system is Hermitian positive definite and
+//          fp32-ill-conditioned at high SNR (cond ~ 3.5e5), so the inverse is formed in float64
+//          on the device by in-place Gauss-Jordan (no pivoting needed for HPD), then rounded once to c64.
+//          It runs once per (pilot pattern, sigma^2).
+// apply  : gather h_ls = y/(x+1e-12) for all B*R*T grids, complex GEMM W[P,P] x h_ls[P,M] on the exact-f32
+//          MFMA pipe (v_mfma_f32_32x32x2_f32; 4 real MFMAs per complex k-pair), then the usual plan-driven
+//          interpolation.  This is the only MFMA-shaped work on the hot path.
+#include "chest_device.h"
+#include "chest_internal.h"
+
+namespace chest {
+
+struct cdd { double x, y; };
+__device__ __forceinline__ cdd zmul(cdd a, cdd b) { return {a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
+
+__global__ void __launch_bounds__(256) gj_init_kernel(int P, const cdd* __restrict__ cov, double s2, cdd* __restrict__ A) {
+    const size_t n = (size_t)P * P;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
+        cdd v = cov[e];
+        if (e / P == e % P) v.x += s2;
+        A[e] = v;
+    }
+}
+
+// pivot step part 1: save the scaled pivot row and the pivot column
+__global__ void __launch_bounds__(256) gj_extract_kernel(int P, int p, const cdd* __restrict__ A, cdd* __restrict__ rowbuf,
+                                                         cdd* __restrict__ colbuf) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= P) return;
+    const cdd piv = A[(size_t)p * P + p];
+    const double d2 = piv.x * piv.x + piv.y * piv.y;
+    const cdd inv = {piv.x / d2, -piv.y / d2};
+    rowbuf[j] = (j == p) ? inv : zmul(A[(size_t)p * P + j], inv);
+    colbuf[j] = A[(size_t)j * P + p];
+}
+
+// pivot step part 2: rank-1 update of the whole matrix (in-place inverse bookkeeping)
+__global__ void __launch_bounds__(256) gj_update_kernel(int P, int p, cdd* __restrict__ A, const cdd* __restrict__ rowbuf,
+                                                        const cdd* __restrict__ colbuf) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = blockIdx.y;
+    if (j >= P) return;
+    const cdd rj = rowbuf[j];
+    cdd v;
+    if (i == p) {
+        v = rj;
+    } else {
+        const cdd ci = colbuf[i];
+        const cdd q = zmul(ci, rj);
+        if (j == p) v = {-q.x, -q.y};
+        else { v = A[(size_t)i * P + j]; v.x -= q.x; v.y -= q.y; }
+    }
+    A[(size_t)i * P + j] = v;
+}
+
+__global__ void __launch_bounds__(256) gj_finish_kernel(int P, const cdd* __restrict__ Ainv, double s2, float2* __restrict__ W) {
+    const size_t n = (size_t)P * P;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
+        const cdd a = Ainv[e];
+        const double diag = (e / P == e % P) ? 1.0 : 0.0;
+        W[e] = make_float2((float)(diag - s2 * a.x), (float)(-s2 * a.y));
+    }
+}
+
+// ---- apply --------------------------------------------------------------------------------------
+// h_ls for every (frame, rx, tx) grid, stored [M][Ppad] (pilot index contiguous = GEMM K dimension).
+__global__ void __launch_bounds__(256)
+gather_ls_kernel(int S, int R, int T, int nsc, int P, int Ppad, const int32_t* __restrict__ pilot_idx,
+                 const float2* __restrict__ rx4d, const float2* __restrict__ tx_pilots, int pilot_stride,
+                 float2* __restrict__ h) {
+    const int m = blockIdx.x;                       // (b*R + r)*T + t
+    const int t = m % T, r = (m / T) % R, b = m / (T * R);
+    const size_t frame_base = (size_t)b * S * R * T * nsc;
+    for (int i = threadIdx.x; i < Ppad; i += blockDim.x) {
+        float2 v = make_float2(0.f, 0.f);
+        if (i < P) {
+            const int g = pilot_idx[i];
+            const int s = g / nsc, k = g - s * nsc;
+            const float2 y = rx4d[frame_base + ((size_t)(s * R + r) * T + t) * nsc + k];
+            const float2 x = tx_pilots[(size_t)b * pilot_stride + i];
+            const float2 xe = make_float2(x.x + 1e-12f, x.y);
+            const float inv = 1.0f / cabs2(xe);
+            v = make_float2((y.x * xe.x + y.y * xe.y) * inv, (y.y * xe.x - y.x * xe.y) * inv);
+        }
+        h[(size_t)m * Ppad + i] = v;
+    }
+}
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+constexpr int GB_M = 64, GB_N = 64, GB_K = 16, GB_LD = GB_K + 1;   // +1 float2 pad: conflict-free ds_read_b64
+
+// C[m][i] = sum_k W[i][k] * Hin[m][k]   (complex, K = Ppad).  Block 256 threads = 4 waves, each a
+// 32x32 tile of the 64(i) x 64(m) block tile; LDS tiles are [row][k] float2 with one pad element.
+__global__ void __launch_bounds__(256)
+cgemm_w_kernel(int P, int Ppad, int M, const float2* __restrict__ W, const float2* __restrict__ Hin,
+               float2* __restrict__ Hout) {
+    __shared__ float2 As[GB_M * GB_LD];
+    __shared__ float2 Bs[GB_N * GB_LD];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int i0 = blockIdx.x * GB_M, m0 = blockIdx.y * GB_N;
+    const int wi = (wave & 1) * 32, wm = (wave >> 1) * 32;
+    f32x16 cre = {0}, cim = {0};
+    const int lrow = tid >> 2;                 // 0..63 : tile row loaded by this thread
+    const int lk = (tid & 3) * 4;              // 0,4,8,12 : first of 4 complex k it loads
+    for (int k0 = 0; k0 < Ppad; k0 += GB_K) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int k = k0 + lk + q;
+            float2 a = make_float2(0.f, 0.f), bv = make_float2(0.f, 0.f);
+            if (i0 + lrow < P && k < P) a = W[(size_t)(i0 + lrow) * P + k];
+            if (m0 + lrow < M && k < Ppad) bv = Hin[(size_t)(m0 + lrow) * Ppad + k];
+            As[lrow * GB_LD + lk + q] = a;
+            Bs[lrow * GB_LD + lk + q] = bv;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < GB_K; kk += 2) {
+            // 32x32x2 operand map: lane l holds A[i = l&31][k = l>>5], B[k = l>>5][j = l&31]
+            const float2 a = As[(wi + (lane & 31)) * GB_LD + kk + (lane >> 5)];
+            const float2 bb = Bs[(wm + (lane & 31)) * GB_LD + kk + (lane >> 5)];
+            cre = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bb.x, cre, 0, 0, 0);
+            cre = __builtin_amdgcn_mfma_f32_32x32x2f32(-a.y, bb.y, cre, 0, 0, 0);
+            cim = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bb.y, cim, 0, 0, 0);
+            cim = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bb.x, cim, 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    // C/D map: col j = lane&31 (the m index), row i = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+    const int m = m0 + wm + (lane & 31);
+    if (m < M) {
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int i = i0 + wi + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+            if (i < P) Hout[(size_t)m * Ppad + i] = make_float2(cre[reg], cim[reg]);
+        }
+    }
+}
+
+// plan-driven interpolation of precomputed pilot values h[m][Ppad] (same arithmetic as estimate_kernel)
+__global__ void __launch_bounds__(256)
+interp_from_pilots_kernel(int S, int R, int T, int nsc, int Ppad, const PatternDev* __restrict__ patterns, int slot,
+                          const float2* __restrict__ h, float2* __restrict__ H_est) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    float2* hp = (float2*)lds_raw;
+    const PatternDev pat = patterns[slot];
+    const int P = pat.P, G = S * nsc, m = blockIdx.x;
+    const int t = m % T, r = (m / T) % R, b = m / (T * R);
+    for (int i = threadIdx.x; i < P; i += blockDim.x) hp[i] = h[(size_t)m * Ppad + i];
+    __syncthreads();
+    const uint16_t *pi0 = pat.plan_idx, *pi1 = pi0 + G, *pi2 = pi1 + G;
+    const float *pw0 = pat.plan_w, *pw1 = pw0 + G, *pw2 = pw1 + G;
+    const size_t frame_base = (size_t)b * S * R * T * nsc;
+    for (int g = threadIdx.x; g < G; g += blockDim.x) {
+        const float2 a0 = hp[pi0[g]], a1 = hp[pi1[g]], a2 = hp[pi2[g]];
+        const float w0 = pw0[g], w1 = pw1[g], w2 = pw2[g];
+        float2 v;
+        v.x = fmaf(w2, a2.x, fmaf(w1, a1.x, w0 * a0.x));
+        v.y = fmaf(w2, a2.y, fmaf(w1, a1.y, w0 * a0.y));
+        const int s = g / nsc, k = g - s * nsc;
+        H_est[frame_base + ((size_t)(s * R + r) * T + t) * nsc + k] = v;
+    }
+}
+
+static inline int pad16(int p) { return (p + 15) & ~15; }
+
+}  // namespace chest
+
+using namespace chest;
+
+extern "C" {
+
+int64_t chest_mmse_full_workspace_bytes(int32_t P) {
+    if (P <= 0) return 0;
+    return (int64_t)sizeof(double) * 2 * ((int64_t)P * P + 2 * (int64_t)P);
+}
+
+int chest_mmse_full_prepare(chest_ctx* ctx, void* stream, int32_t P, const double* cov, float snr_db, float* W,
+                            double* workspace, int64_t workspace_bytes) {
+    if (!ctx || P <= 0 || !cov || !W || !workspace) { set_error("chest_mmse_full_prepare: bad argument"); return CHEST_EINVAL; }
+    if (workspace_bytes < chest_mmse_full_workspace_bytes(P)) {
+        set_error("chest_mmse_full_prepare: workspace %lld B < %lld B", (long long)workspace_bytes,
+                  (long long)chest_mmse_full_workspace_bytes(P));
+        return CHEST_EINVAL;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const double s2 = 1.0 / pow(10.0, (double)snr_db / 10.0);              // (:174-175)
+    cdd* A = (cdd*)workspace;
+    cdd* rowbuf = A + (size_t)P * P;
+    cdd* colbuf = rowbuf + P;
+    const unsigned nb = (unsigned)(((size_t)P * P + 255) / 256 > 4096 ? 4096 : ((size_t)P * P + 255) / 256);
+    hipLaunchKernelGGL(gj_init_kernel, dim3(nb), dim3(256), 0, st, P, (const cdd*)cov, s2, A);
+    const unsigned bx = (unsigned)((P + 255) / 256);
+    for (int p = 0; p < P; ++p) {
+        hipLaunchKernelGGL(gj_extract_kernel, dim3(bx), dim3(256), 0, st, P, p, A, rowbuf, colbuf);
+        hipLaunchKernelGGL(gj_update_kernel, dim3(bx, (unsigned)P), dim3(256), 0, st, P, p, A, rowbuf, colbuf);
+    }
+    hipLaunchKernelGGL(gj_finish_kernel, dim3(nb), dim3(256), 0, st, P, A, s2, (float2*)W);
+    CHEST_HIP(hipGetLastError());
+    return CHEST_OK;
+}
+
+int chest_mmse_full_apply(chest_ctx* ctx, void* stream, int32_t B, const float* rx4d, const float* tx_pilots,
+                          int32_t pilot_stride, int32_t slot, const float* W, float* h_scratch, float* H_est) {
+    if (!ctx || B < 0 || (B > 0 && (!rx4d || !tx_pilots || !W || !h_scratch || !H_est))) {
+        set_error("chest_mmse_full_apply: bad argument");
+        return CHEST_EINVAL;
+    }
+    if (B == 0) return CHEST_OK;
+    if (slot < 0 || slot >= (int)ctx->patterns.size() || ctx->patterns[slot].dev.slot == nullptr ||
+        ctx->patterns[slot].dev.plan_idx == nullptr) {
+        set_error("pattern slot %d is not set or has no plan", slot);
+        return CHEST_ESTATE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const auto& f = ctx->fp;
+    const PatternDev& pd = ctx->patterns[slot].dev;
+    const int P = pd.P, Ppad = pad16(P), M = B * f.R * f.T;
+    float2* h_in = (float2*)h_scratch;
+    float2* h_out = h_in + (size_t)M * Ppad;
+    hipLaunchKernelGGL(gather_ls_kernel, dim3(M), dim3(256), 0, st, f.S, f.R, f.T, f.nsc, P, Ppad, pd.pilot_idx,
+                       (const float2*)rx4d, (const float2*)tx_pilots, pilot_stride, h_in);
+    hipLaunchKernelGGL(cgemm_w_kernel, dim3((P + GB_M - 1) / GB_M, (M + GB_N - 1) / GB_N), dim3(256), 0, st, P, Ppad, M,
+                       (const float2*)W, h_in, h_out);
+    const size_t lds = (size_t)P * sizeof(float2);
+    if (lds > 64 * 1024)
+        CHEST_HIP(hipFuncSetAttribute((const void*)interp_from_pilots_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(interp_from_pilots_kernel, dim3(M), dim3(256), lds, st, f.S, f.R, f.T, f.nsc, Ppad, ctx->d_patterns,
+                       slot, h_out, (float2*)H_est);
+    CHEST_HIP(hipGetLastError());
+    return CHEST_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,363 @@
+"""Batch-first Python front end of the MI355X engine (libchest.so).
+
+``Engine`` owns one C-ABI context per (device, fft, cp, S, U, T, R) plus the uploaded pilot
+patterns / interpolation plans.  Tensors live in HBM as torch tensors (torch is only the allocator
+and stream provider); every numeric step is a hand-written HIP kernel behind ``include/chest.h``.
+
+Reference interfaces served (paths relative to the reference checkout):
+  run_frames            one ``simulate_transmission`` (+LS +MMSE) per frame   src/channel_simulator.py:348-421,
+                        src/baseline_estimators.py:83-117, :232-270, loop body src/dataset_generator.py:34-89
+  estimate              LSEstimator.estimate / MMSEEstimator.estimate          src/baseline_estimators.py:83-117, :232-270
+  at_pilots             *.estimate_at_pilots                                   :23-42, :155-196
+  error_sums            evaluate_estimator                                     :315-337
+  apply_channel         MIMOChannel.apply_channel                              src/channel_simulator.py:313-345
+  time_varying_channel  ChannelModel.generate_time_varying_channel             :84-127
+  ofdm_modulate/demod   OFDMSystem.modulate / demodulate                       :150-203
+  equalize              equalize_channel                                       src/baseline_estimators.py:273-312
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+
+from . import _native as N
+from . import interp_plan
+
+DESC_DTYPE = np.dtype([("channel_type", "<i4"), ("doppler_hz", "<f4"), ("snr_db", "<f4"), ("pattern_slot", "<i4")])
+ALL_OUTPUTS = ("tx", "rx", "H", "H_ls", "H_mmse", "pilot_symbols", "pilot_mask", "metrics")
+
+
+@dataclass(frozen=True)
+class Geometry:
+    fft_size: int = 1024
+    cp_length: int = 72
+    num_symbols: int = 14
+    useful_subcarriers: int = 600
+    subcarrier_spacing: float = 15000.0
+    num_tx: int = 2
+    num_rx: int = 2
+
+    @property
+    def num_sc(self) -> int:
+        return 2 * (self.useful_subcarriers // 2) - 1
+
+    @property
+    def grid(self) -> int:
+        return self.num_symbols * self.num_sc
+
+
+def channel_code(channel_type) -> int:
+    """'EPA'/'EVA'/'ETU' (any case) -> ABI code; unknown names raise KeyError like the reference's
+    CHANNEL_PROFILES lookup (src/channel_simulator.py:67-72)."""
+    if isinstance(channel_type, (int, np.integer)):
+        return int(channel_type)
+    return N.CHANNEL_CODES[str(channel_type).upper()]
+
+
+def make_descs(channel_type, doppler_hz, snr_db, pattern_slot, n=None):
+    """Host frame descriptors from scalars or per-frame sequences."""
+    if n is None:
+        n = max(np.size(channel_type), np.size(doppler_hz), np.size(snr_db), np.size(pattern_slot))
+    d = np.empty(n, dtype=DESC_DTYPE)
+    if np.ndim(channel_type) == 0:
+        d["channel_type"] = channel_code(channel_type)
+    else:
+        d["channel_type"] = [channel_code(c) for c in channel_type]
+    d["doppler_hz"] = doppler_hz
+    d["snr_db"] = snr_db
+    d["pattern_slot"] = pattern_slot
+    return d
+
+
+class Engine:
+    def __init__(self, geometry: Geometry, device=None):
+        if not torch.cuda.is_available():
+            raise N.ChestError("no HIP device visible: the MI355X engine has no CPU fallback")
+        self.geom = geometry
+        self.device = torch.device("cuda", torch.cuda.current_device() if device is None else
+                                   (device if isinstance(device, int) else torch.device(device).index or 0))
+        cfg = N.Config(geometry.fft_size, geometry.cp_length, geometry.num_symbols, geometry.useful_subcarriers,
+                       float(geometry.subcarrier_spacing), geometry.num_tx, geometry.num_rx, self.device.index)
+        h = C.c_void_p()
+        N.check(N.lib().chest_create(C.byref(cfg), C.byref(h)), "chest_create")
+        self._h = h
+        self._slots = {}          # pattern key -> slot
+        self._slot_P = {}
+        self._next_slot = 0
+        nsc = C.c_int32()
+        N.check(N.lib().chest_get_used_indices(self._h, C.byref(nsc), None))
+        assert nsc.value == geometry.num_sc
+
+    # ---- lifetime ----------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            N.lib().chest_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- host-side tables -------------------------------------------------------------------------
+    def used_indices(self) -> np.ndarray:
+        out = np.empty(self.geom.num_sc, dtype=np.int64)
+        N.check(N.lib().chest_get_used_indices(self._h, None, out.ctypes.data_as(C.POINTER(C.c_int64))))
+        return out
+
+    def tap_table(self, channel_type):
+        n = C.c_int32()
+        d = (C.c_int32 * N.MAX_PATHS)()
+        p = (C.c_double * N.MAX_PATHS)()
+        N.check(N.lib().chest_get_tap_table(self._h, channel_code(channel_type), C.byref(n), d, p), "chest_get_tap_table")
+        return np.array(p[: n.value]), np.array(d[: n.value], dtype=np.int64)
+
+    # ---- patterns -----------------------------------------------------------------------------------
+    def set_pattern(self, slot: int, pilot_idx, plan=None):
+        """Upload a sorted flat pilot index list (PilotPattern.pilot_indices) and optionally its plan."""
+        pi = np.ascontiguousarray(pilot_idx, dtype=np.int32)
+        if plan is None:
+            pidx = pw = None
+        else:
+            pidx = np.ascontiguousarray(plan[0], dtype=np.uint16)
+            pw = np.ascontiguousarray(plan[1], dtype=np.float32)
+            if pidx.shape != (3, self.geom.grid) or pw.shape != (3, self.geom.grid):
+                raise ValueError(f"plan must be two (3, {self.geom.grid}) arrays")
+        N.check(N.lib().chest_pattern_set(self._h, int(slot), pi.ctypes.data, len(pi),
+                                          None if pidx is None else pidx.ctypes.data,
+                                          None if pw is None else pw.ctypes.data), "chest_pattern_set")
+        self._slot_P[int(slot)] = len(pi)
+        self._next_slot = max(self._next_slot, int(slot) + 1)
+        return int(slot)
+
+    def pattern_slot(self, pilot_idx, method="linear", with_plan=True):
+        """Slot for a pattern, uploading it (and building its plan) on first use."""
+        key = interp_plan.pattern_key(pilot_idx, method if with_plan else None)
+        slot = self._slots.get(key)
+        if slot is None:
+            plan = None
+            if with_plan:
+                S, nsc = self.geom.num_symbols, self.geom.num_sc
+                ps, pk = np.unravel_index(np.asarray(pilot_idx, dtype=np.int64), (S, nsc))
+                plan = interp_plan.build_plan(ps, pk, S, nsc, method)
+            slot = self.set_pattern(self._next_slot, pilot_idx, plan)
+            self._slots[key] = slot
+        return slot
+
+    def num_pilots(self, slot: int) -> int:
+        return self._slot_P[int(slot)]
+
+    def check_status(self):
+        st = C.c_int32()
+        N.check(N.lib().chest_get_status(self._h, C.byref(st)), "chest_get_status")
+        if st.value == 1:
+            raise N.ChestError("a kernel met an invalid frame descriptor (channel_type or pattern_slot)")
+        if st.value == 2:
+            raise N.ChestError("estimates were requested for a pattern that has no interpolation plan")
+
+    # ---- helpers ----------------------------------------------------------------------------------
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _dev(self, a, dtype):
+        """Host array / tensor -> contiguous device tensor of `dtype` (no copy if already there)."""
+        if isinstance(a, torch.Tensor):
+            return a.to(device=self.device, dtype=dtype).contiguous()
+        return torch.from_numpy(np.ascontiguousarray(a)).to(device=self.device, dtype=dtype).contiguous()
+
+    def _c64(self, a):
+        return self._dev(a, torch.complex64)
+
+    def empty_c64(self, *shape):
+        return torch.empty(shape, dtype=torch.complex64, device=self.device)
+
+    # ---- fused frame pipeline -------------------------------------------------------------------------
+    def run_frames(self, descs, seed=0, frame_offset=0, injected=None, outputs=ALL_OUTPUTS, out=None, check=True):
+        """Run ``len(descs)`` frames.  ``descs``: numpy DESC_DTYPE array or a device uint8/int32 tensor
+        holding the same bytes.  ``injected``: dict with any of u_sym [B,G], u_angle/u_phase [B,L,T,R,20],
+        n_re/n_im [B,S,R,nsc] (float arrays; reference draw order).  Returns a dict of device tensors.
+        ``out`` may carry pre-allocated tensors to reuse."""
+        g = self.geom
+        if isinstance(descs, torch.Tensor):
+            d_dev = descs
+            B = descs.numel() * descs.element_size() // DESC_DTYPE.itemsize
+        else:
+            descs = np.ascontiguousarray(descs, dtype=DESC_DTYPE)
+            B = len(descs)
+            d_dev = torch.from_numpy(descs.view(np.uint8).copy()).to(self.device)
+        S, T, R, nsc, G = g.num_symbols, g.num_tx, g.num_rx, g.num_sc, g.grid
+        pmax = max(self._slot_P.values()) if self._slot_P else 0
+        shapes = {"tx": ((B, S, T, nsc), torch.complex64), "rx": ((B, S, R, nsc), torch.complex64),
+                  "H": ((B, S, R, T, nsc), torch.complex64), "H_ls": ((B, S, R, T, nsc), torch.complex64),
+                  "H_mmse": ((B, S, R, T, nsc), torch.complex64), "pilot_symbols": ((B, pmax), torch.complex64),
+                  "pilot_mask": ((B, S, nsc), torch.uint8), "metrics": ((B, N.NUM_METRICS), torch.float32)}
+        res = {} if out is None else dict(out)
+        fo = N.FrameOutputs()
+        fo.pilot_stride = pmax
+        for name in outputs:
+            if name not in shapes:
+                raise ValueError(f"unknown output {name!r}")
+            shp, dt = shapes[name]
+            t = res.get(name)
+            if t is None:
+                t = (torch.zeros if name == "pilot_symbols" else torch.empty)(shp, dtype=dt, device=self.device)
+                res[name] = t
+            elif tuple(t.shape) != shp or t.dtype != dt or not t.is_contiguous():
+                raise ValueError(f"pre-allocated output {name!r} has the wrong shape/dtype")
+            setattr(fo, name, t.data_ptr())
+        keep = []
+        inj_p = None
+        if injected:
+            inj = N.Injected()
+            for name in ("u_sym", "u_angle", "u_phase", "n_re", "n_im"):
+                a = injected.get(name)
+                if a is None:
+                    continue
+                t = self._dev(a, torch.float32)
+                keep.append(t)
+                setattr(inj, name, t.data_ptr())
+                if name == "u_angle":
+                    if t.dim() != 5 or t.shape[0] != B or tuple(t.shape[2:]) != (T, R, N.NUM_OSC):
+                        raise ValueError("u_angle must be [B, paths, T, R, 20]")
+                    inj.inj_paths = t.shape[1]
+                if name == "u_sym" and tuple(t.shape) != (B, G):
+                    raise ValueError(f"u_sym must be [B, {G}]")
+                if name in ("n_re", "n_im") and tuple(t.shape) != (B, S, R, nsc):
+                    raise ValueError("n_re/n_im must be [B, S, R, nsc]")
+            inj_p = C.byref(inj)
+        N.check(N.lib().chest_frames_run(self._h, self._stream(), B, d_dev.data_ptr(), int(seed) & (2**64 - 1),
+                                         int(frame_offset), inj_p, C.byref(fo)), "chest_frames_run")
+        if check:
+            self.check_status()       # synchronises; pass check=False inside timed loops
+        return res
+
+    # ---- stand-alone estimator surface ---------------------------------------------------------------
+    def estimate(self, rx4d, tx_pilots, slot, mmse=False, snr_db=10.0):
+        g = self.geom
+        rx = self._c64(rx4d)
+        if rx.dim() == 4:
+            rx = rx.unsqueeze(0)
+        B = rx.shape[0]
+        if tuple(rx.shape[1:]) != (g.num_symbols, g.num_rx, g.num_tx, g.num_sc):
+            raise ValueError(f"rx_symbols must be (S,R,T,nsc)={(g.num_symbols, g.num_rx, g.num_tx, g.num_sc)}, got {tuple(rx.shape[1:])}")
+        tp = self._c64(tx_pilots)
+        P = self.num_pilots(slot)
+        if tp.dim() == 1:
+            stride = 0
+            if tp.numel() != P:
+                raise ValueError(f"tx_pilots has {tp.numel()} entries, the pattern has {P} pilots")
+        else:
+            if tuple(tp.shape) != (B, P):
+                raise ValueError(f"tx_pilots must be [{B}, {P}]")
+            stride = P
+        out = torch.empty_like(rx)
+        N.check(N.lib().chest_estimate_batch(self._h, self._stream(), B, rx.data_ptr(), tp.data_ptr(), stride,
+                                             int(slot), int(bool(mmse)), float(snr_db), out.data_ptr()),
+                "chest_estimate_batch")
+        return out
+
+    def at_pilots(self, rx_pilots, tx_pilots, mmse=False, snr_db=10.0):
+        rx = self._c64(rx_pilots).reshape(-1)
+        tx = self._c64(tx_pilots).reshape(-1)
+        if rx.numel() != tx.numel():
+            raise ValueError("rx_pilots and tx_pilots differ in length")
+        out = torch.empty_like(rx)
+        N.check(N.lib().chest_at_pilots(self._h, self._stream(), rx.numel(), rx.data_ptr(), tx.data_ptr(),
+                                        int(bool(mmse)), float(snr_db), out.data_ptr()), "chest_at_pilots")
+        return out
+
+    def error_sums(self, H_true, H_est):
+        a = self._c64(H_true).reshape(-1)
+        b = self._c64(H_est).reshape(-1)
+        if a.numel() != b.numel():
+            raise ValueError("H_true and H_est differ in size")
+        out = torch.empty(2, dtype=torch.float64, device=self.device)
+        N.check(N.lib().chest_error_sums(self._h, self._stream(), a.numel(), a.data_ptr(), b.data_ptr(), out.data_ptr()),
+                "chest_error_sums")
+        return out
+
+    # ---- rest of the simulator surface ---------------------------------------------------------------
+    def apply_channel(self, tx, H, snr_db, n_re=None, n_im=None, seed=0, frame_offset=0):
+        g = self.geom
+        txd, Hd = self._c64(tx), self._c64(H)
+        if txd.dim() == 3:
+            txd, Hd = txd.unsqueeze(0), Hd.unsqueeze(0)
+        B = txd.shape[0]
+        if tuple(txd.shape[1:]) != (g.num_symbols, g.num_tx, g.num_sc) or \
+                tuple(Hd.shape[1:]) != (g.num_symbols, g.num_rx, g.num_tx, g.num_sc):
+            raise ValueError("tx must be (S,T,nsc) and H (S,R,T,nsc) for this engine geometry")
+        snr = self._dev(np.broadcast_to(np.asarray(snr_db, dtype=np.float32), (B,)).copy(), torch.float32)
+        nr = None if n_re is None else self._dev(n_re, torch.float32)
+        ni = None if n_im is None else self._dev(n_im, torch.float32)
+        rx = self.empty_c64(B, g.num_symbols, g.num_rx, g.num_sc)
+        N.check(N.lib().chest_apply_channel(self._h, self._stream(), B, txd.data_ptr(), Hd.data_ptr(), snr.data_ptr(),
+                                            None if nr is None else nr.data_ptr(), None if ni is None else ni.data_ptr(),
+                                            int(seed), int(frame_offset), rx.data_ptr()), "chest_apply_channel")
+        return rx
+
+    def time_varying_channel(self, channel_type, doppler_hz, num_samples, num_tx, num_rx, u_angle=None, u_phase=None,
+                             seed=0, frame_index=0):
+        code = channel_code(channel_type)
+        _, d = self.tap_table(code)
+        D1 = int(d.max()) + 1
+        ua = None if u_angle is None else self._dev(u_angle, torch.float32)
+        up = None if u_phase is None else self._dev(u_phase, torch.float32)
+        if ua is not None and tuple(ua.shape) != (len(d), num_tx, num_rx, N.NUM_OSC):
+            raise ValueError(f"u_angle must be [{len(d)}, {num_tx}, {num_rx}, 20]")
+        out = self.empty_c64(int(num_samples), num_rx, num_tx, D1)
+        N.check(N.lib().chest_time_varying_channel(self._h, self._stream(), code, float(doppler_hz), int(num_samples),
+                                                   int(num_tx), int(num_rx), None if ua is None else ua.data_ptr(),
+                                                   None if up is None else up.data_ptr(), int(seed), int(frame_index),
+                                                   out.data_ptr()), "chest_time_varying_channel")
+        return out
+
+    def ofdm_modulate(self, symbols):
+        g = self.geom
+        s = self._c64(symbols)
+        if s.dim() != 2 or s.shape[1] != g.num_sc:
+            raise ValueError(f"symbols must be (n, {g.num_sc})")
+        out = self.empty_c64(s.shape[0], g.fft_size + g.cp_length)
+        N.check(N.lib().chest_ofdm_modulate(self._h, self._stream(), s.shape[0], s.data_ptr(), out.data_ptr()),
+                "chest_ofdm_modulate")
+        return out
+
+    def ofdm_demodulate(self, received):
+        g = self.geom
+        r = self._c64(received)
+        if r.dim() != 2 or r.shape[1] != g.fft_size + g.cp_length:
+            raise ValueError(f"received_signal must be (n, {g.fft_size + g.cp_length})")
+        out = self.empty_c64(r.shape[0], g.num_sc)
+        N.check(N.lib().chest_ofdm_demodulate(self._h, self._stream(), r.shape[0], r.data_ptr(), out.data_ptr()),
+                "chest_ofdm_demodulate")
+        return out
+
+    def equalize(self, rx, H_est, method="zf"):
+        g = self.geom
+        if method not in ("zf", "mmse"):
+            raise ValueError(f"Unknown equalization method: {method}")
+        r, H = self._c64(rx), self._c64(H_est)
+        if r.dim() == 3:
+            r, H = r.unsqueeze(0), H.unsqueeze(0)
+        B = r.shape[0]
+        out = self.empty_c64(B, g.num_symbols, g.num_tx, g.num_sc)
+        N.check(N.lib().chest_equalize(self._h, self._stream(), B, r.data_ptr(), H.data_ptr(),
+                                       0 if method == "zf" else 1, out.data_ptr()), "chest_equalize")
+        return out
+
+
+_ENGINES = {}
+
+
+def get_engine(geometry: Geometry, device=None) -> Engine:
+    """Process-wide engine cache keyed by geometry and device."""
+    dev = torch.cuda.current_device() if device is None else device
+    key = (geometry, dev)
+    e = _ENGINES.get(key)
+    if e is None:
+        e = Engine(geometry, dev)
+        _ENGINES[key] = e
+    return e

@@ -1,0 +1,85 @@
+"""Interpolation plans: the geometry-only part of ``scipy.interpolate.griddata`` done once per
+pilot pattern on the host, so that the GPU applies it as a 3-point gather.
+
+``LSEstimator.interpolate_channel`` (reference src/baseline_estimators.py:44-81) calls
+``griddata(points=(sym, sc) integer coordinates, xi=all (sym, sc) row-major, method, fill_value=0)``
+twice per antenna pair.  For ``'linear'`` that is: Qhull Delaunay triangulation of the pilots
+(options "Qbb Qc Qz Q12", no rescaling), locate each grid point's simplex, barycentric weights,
+0 outside the convex hull.  The pilots sit on an integer lattice, so the triangulation is massively
+degenerate and only Qhull's own tie-breaking reproduces the reference; the plan is therefore
+extracted from ``scipy.spatial.Delaunay`` itself.  ``'nearest'`` is a cKDTree query
+(``NearestNDInterpolator``), a plan with weights (1, 0, 0).
+
+A plan is ``(idx uint16[3, G], w float32[3, G])`` with G = S*nsc in row-major grid order.
+"""
+from __future__ import annotations
+
+import hashlib
+
+import numpy as np
+
+_CACHE = {}
+_CACHE_MAX = 256
+
+
+def _grid_points(S, nsc):
+    ss, kk = np.meshgrid(np.arange(S), np.arange(nsc), indexing="ij")
+    return np.column_stack([ss.ravel(), kk.ravel()]).astype(np.float64)
+
+
+def linear_plan(pilot_sym, pilot_sc, S, nsc):
+    """Plan equal to griddata(..., method='linear', fill_value=0.0).  Raises scipy's QhullError for
+    degenerate pilot sets (fewer than 3 pilots, all collinear), like the reference does."""
+    from scipy.spatial import Delaunay
+    pts = np.column_stack([np.asarray(pilot_sym), np.asarray(pilot_sc)]).astype(np.float64)
+    tri = Delaunay(pts)
+    xi = _grid_points(S, nsc)
+    simp = tri.find_simplex(xi)
+    inside = simp >= 0
+    sj = np.where(inside, simp, 0)
+    Tm = tri.transform[sj]                                  # (G, 3, 2)
+    bary = np.einsum("gij,gj->gi", Tm[:, :2, :], xi - Tm[:, 2, :])
+    w = np.concatenate([bary, 1.0 - bary.sum(axis=1, keepdims=True)], axis=1)
+    w[~inside] = 0.0
+    idx = tri.simplices[sj].astype(np.int64)
+    idx[~inside] = 0
+    # a simplex may be flagged degenerate by Qhull (nan transform); griddata yields nan there
+    return np.ascontiguousarray(idx.T.astype(np.uint16)), np.ascontiguousarray(w.T.astype(np.float32))
+
+
+def nearest_plan(pilot_sym, pilot_sc, S, nsc):
+    """Plan equal to griddata(..., method='nearest')."""
+    from scipy.spatial import cKDTree
+    pts = np.column_stack([np.asarray(pilot_sym), np.asarray(pilot_sc)]).astype(np.float64)
+    _, i = cKDTree(pts).query(_grid_points(S, nsc))
+    G = S * nsc
+    idx = np.empty((3, G), dtype=np.uint16)
+    idx[:] = i.astype(np.uint16)
+    w = np.zeros((3, G), dtype=np.float32)
+    w[0] = 1.0
+    return idx, w
+
+
+def build_plan(pilot_sym, pilot_sc, S, nsc, method="linear"):
+    """Cached plan for one pattern.  'cubic' (Clough-Tocher) has no plan form yet."""
+    if method not in ("linear", "nearest"):
+        if method == "cubic":
+            raise NotImplementedError(
+                "interpolation_method='cubic' (Clough-Tocher) is not implemented by the MI355X engine yet; "
+                "use 'linear' or 'nearest'")
+        raise ValueError(f"Unknown interpolation method: {method}")
+    ps = np.ascontiguousarray(pilot_sym, dtype=np.int64)
+    pk = np.ascontiguousarray(pilot_sc, dtype=np.int64)
+    key = (method, S, nsc, hashlib.blake2b(ps.tobytes() + pk.tobytes(), digest_size=16).digest())
+    hit = _CACHE.get(key)
+    if hit is None:
+        hit = linear_plan(ps, pk, S, nsc) if method == "linear" else nearest_plan(ps, pk, S, nsc)
+        if len(_CACHE) >= _CACHE_MAX:
+            _CACHE.pop(next(iter(_CACHE)))
+        _CACHE[key] = hit
+    return hit
+
+
+def pattern_key(pilot_idx, method):
+    a = np.ascontiguousarray(pilot_idx, dtype=np.int64)
+    return (method, hashlib.blake2b(a.tobytes(), digest_size=16).digest())

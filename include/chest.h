@@ -1,0 +1,204 @@
+/*
+ * chest.h -- C ABI of the MI355X-native OFDM channel-simulation + LS/MMSE estimation engine.
+ *
+ * This is the drop-in boundary.  The reference has no FFI of its own (it is pure Python), so each
+ * entry point below names the reference *Python* interface it replaces (paths relative to the
+ * reference checkout).  The Python mirror of those interfaces lives in
+ * channel-estimation-in-5g-network_amd/{channel_simulator,baseline_estimators,dataset_generator}.py
+ * and binds this library with ctypes (see INTEGRATION.md for the stub).
+ *
+ * Conventions
+ *   - every function returns 0 on success and a negative CHEST_E* code on failure;
+ *     chest_last_error() returns a thread-local message.  Nothing throws across the ABI.
+ *   - all tensor arguments are raw DEVICE pointers (hipMalloc / torch .data_ptr()), caller-owned,
+ *     row-major, complex64 stored as interleaved (re, im) float pairs, unless marked HOST.
+ *   - launches are asynchronous on the caller's hipStream_t (passed as void*, NULL = default stream);
+ *     no call in the "launch" group allocates, frees or synchronises (graph-capturable).
+ *   - one context per (device, fft_size, cp_length, num_symbols, useful_subcarriers, num_tx, num_rx);
+ *     a context is used by one host thread at a time.
+ *
+ * Shapes use S = num_symbols, nsc = useful_subcarriers-1 (DC removed), T/R = tx/rx antennas,
+ * P = pilots of the frame's pattern, G = S*nsc.
+ */
+#ifndef CHEST_H_
+#define CHEST_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CHEST_ABI_VERSION 1
+
+#define CHEST_OK 0
+#define CHEST_EINVAL (-1)   /* bad argument / unsupported shape */
+#define CHEST_EHIP (-2)     /* HIP runtime error (message has the hipError string) */
+#define CHEST_ENOMEM (-3)
+#define CHEST_ESTATE (-4)   /* e.g. pattern slot not set */
+
+#define CHEST_MAX_PATHS 16
+#define CHEST_NUM_OSC 20    /* Jakes oscillators, src/channel_simulator.py:100 */
+#define CHEST_MAX_SYMBOLS 32
+
+/* channel_type codes (ChannelModel.CHANNEL_PROFILES keys, src/channel_simulator.py:41-54) */
+#define CHEST_EPA 0
+#define CHEST_EVA 1
+#define CHEST_ETU 2
+#define CHEST_NUM_PROFILES 3
+
+typedef struct chest_ctx chest_ctx;
+
+/* OFDMConfig + MIMOConfig (src/channel_simulator.py:17-31) plus the device ordinal. */
+typedef struct chest_config {
+    int32_t fft_size;            /* power of two, <= 4096 */
+    int32_t cp_length;
+    int32_t num_symbols;         /* <= CHEST_MAX_SYMBOLS */
+    int32_t useful_subcarriers;
+    double subcarrier_spacing;   /* Hz */
+    int32_t num_tx;              /* 1..8 */
+    int32_t num_rx;              /* 1..8 */
+    int32_t device;              /* HIP device ordinal */
+} chest_config;
+
+/* One frame = one simulate_transmission call (src/channel_simulator.py:348-421). 16 bytes. */
+typedef struct chest_frame_desc {
+    int32_t channel_type;        /* CHEST_EPA / EVA / ETU */
+    float doppler_hz;
+    float snr_db;
+    int32_t pattern_slot;        /* which uploaded PilotPattern + interpolation plan */
+} chest_frame_desc;
+
+/* Optional injected random inputs (parity mode).  NULL struct pointer, or any NULL member, means
+ * "draw that stream from the on-device counter-based generator (Philox4x32-10 keyed by
+ * seed / global frame index / stream)".  Uniforms are the raw [0,1) draws BEFORE the reference's
+ * 2*pi scaling; the order inside each buffer is the reference's draw order. */
+typedef struct chest_injected {
+    const float* u_sym;          /* [B][G]: first P = pilot phases (:395), then G-P data phases (:399) */
+    const float* u_angle;        /* [B][inj_paths][T][R][20] (:109), path -> tx -> rx order (:102-107) */
+    const float* u_phase;        /* [B][inj_paths][T][R][20] (:110) */
+    const float* n_re;           /* [B][S][R][nsc] standard normals, real block (:342) */
+    const float* n_im;           /* [B][S][R][nsc] imaginary block */
+    int32_t inj_paths;           /* leading path dimension of u_angle/u_phase */
+} chest_injected;
+
+/* Outputs of the fused frame pipeline; any pointer may be NULL to skip that store. */
+typedef struct chest_frame_outputs {
+    float* tx;                   /* [B][S][T][nsc] c64  'tx_symbols' */
+    float* rx;                   /* [B][S][R][nsc] c64  'rx_symbols' */
+    float* H;                    /* [B][S][R][T][nsc] c64 'channel'  */
+    float* H_ls;                 /* [B][S][R][T][nsc] c64 LSEstimator('linear'|'nearest' per plan).estimate */
+    float* H_mmse;               /* [B][S][R][T][nsc] c64 MMSEEstimator().estimate (diagonal statistics) */
+    float* pilot_symbols;        /* [B][pilot_stride] c64, first P valid */
+    uint8_t* pilot_mask;         /* [B][G] 0/1 */
+    float* metrics;              /* [B][CHEST_NUM_METRICS] see below */
+    int32_t pilot_stride;
+} chest_frame_outputs;
+
+/* metrics[b][*] (float32) */
+#define CHEST_M_SUM_H2 0         /* sum |H|^2 over (S,R,T,nsc) */
+#define CHEST_M_SUM_ERR_LS 1     /* sum |H - H_ls|^2 */
+#define CHEST_M_SUM_ERR_MMSE 2   /* sum |H - H_mmse|^2 */
+#define CHEST_M_SIGNAL_POWER 3   /* mean |y|^2 before noise (src/channel_simulator.py:337) */
+#define CHEST_M_NOISE_STD 4      /* per-component noise std (:340) */
+#define CHEST_M_ALPHA0 5         /* MMSE shrinkage p/(p+sigma^2) of rx antenna 0 */
+#define CHEST_M_COUNT 6          /* S*R*T*nsc as float */
+#define CHEST_M_RESERVED 7
+#define CHEST_NUM_METRICS 8
+
+/* ---- setup group (may allocate / synchronise) -------------------------------------------- */
+
+/* Replaces: OFDMConfig/MIMOConfig/OFDMSystem.__init__/ChannelModel.__init__ table building
+ * (src/channel_simulator.py:17-31, :56-82, :133-148). */
+int chest_create(const chest_config* cfg, chest_ctx** out);
+void chest_destroy(chest_ctx* ctx);
+const char* chest_last_error(void);
+int chest_abi_version(void);
+
+/* nsc and the fftshift-ed used bin indices (OFDMSystem.used_indices, :142-148). HOST out[nsc] or NULL. */
+int chest_get_used_indices(chest_ctx* ctx, int32_t* num_sc, int64_t* out);
+/* ChannelModel.delay_samples / powers_linear for this context's sampling rate (:75-82). HOST outputs. */
+int chest_get_tap_table(chest_ctx* ctx, int32_t channel_type, int32_t* num_paths,
+                        int32_t* delay_samples /*[CHEST_MAX_PATHS]*/, double* powers_linear /*[CHEST_MAX_PATHS]*/);
+
+/* Upload one PilotPattern (:209-236) and its interpolation plan into `slot`.
+ * pilot_idx: HOST int32[P], sorted flat indices into (S, nsc).
+ * plan_idx : HOST uint16[3][G] pilot ordinals; plan_w: HOST float[3][G] weights
+ *            (griddata 'linear' = barycentric weights of the Qhull simplex, 0 outside the hull;
+ *             'nearest' = (1,0,0)); both may be NULL for simulation-only use. */
+int chest_pattern_set(chest_ctx* ctx, int32_t slot, const int32_t* pilot_idx, int32_t num_pilots,
+                      const uint16_t* plan_idx, const float* plan_w);
+int chest_pattern_num_pilots(chest_ctx* ctx, int32_t slot);
+/* Device-side error word set by kernels that met a bad frame descriptor (1) or a pattern without a
+ * plan (2); reading it synchronises the device and clears it. HOST out. */
+int chest_get_status(chest_ctx* ctx, int32_t* status);
+
+/* ---- launch group (asynchronous, no allocation) -------------------------------------------- */
+
+/* Fused frame pipeline: simulate_transmission (:348-421) -> LSEstimator.estimate
+ * (src/baseline_estimators.py:83-117) -> MMSEEstimator.estimate (:232-270) ->
+ * evaluate_estimator partial sums (:326-337), i.e. the loop body of
+ * ChannelEstimationDataset.generate_sample (src/dataset_generator.py:34-89), for `num_frames`
+ * independent frames.  descs: DEVICE chest_frame_desc[num_frames].  Frame b uses random streams
+ * keyed by (seed, frame_offset + b), so any sharding of a frame range gives identical frames. */
+int chest_frames_run(chest_ctx* ctx, void* stream, int32_t num_frames, const chest_frame_desc* descs,
+                     uint64_t seed, uint64_t frame_offset, const chest_injected* inj,
+                     const chest_frame_outputs* out);
+
+/* LSEstimator.estimate / MMSEEstimator.estimate on caller-supplied grids (any rx_4d, not only the
+ * tx-repeated one): rx4d [B][S][R][T][nsc] c64, tx_pilots [B][pilot_stride] c64 (pilot_stride 0 =
+ * shared by all frames), one pattern slot for the batch.  mmse != 0 applies the diagonal-statistics
+ * MMSE filter with sigma^2 = 10^(-snr_db/10) (:174-180) before interpolation. */
+int chest_estimate_batch(chest_ctx* ctx, void* stream, int32_t num_frames, const float* rx4d,
+                         const float* tx_pilots, int32_t pilot_stride, int32_t pattern_slot,
+                         int32_t mmse, float snr_db, float* H_est);
+
+/* LSEstimator.estimate_at_pilots / MMSEEstimator.estimate_at_pilots (:23-42, :155-196, diagonal
+ * statistics) on n pilot observations: out = rx/(tx+1e-12) [* p/(p+sigma^2)]. */
+int chest_at_pilots(chest_ctx* ctx, void* stream, int32_t n, const float* rx_pilots, const float* tx_pilots,
+                    int32_t mmse, float snr_db, float* out);
+
+/* evaluate_estimator partial sums (:326-337): out[0] = sum|H_true-H_est|^2, out[1] = sum|H_true|^2
+ * over n complex elements (float64 accumulators, DEVICE double[2], zeroed by the call). */
+int chest_error_sums(chest_ctx* ctx, void* stream, int64_t n, const float* H_true, const float* H_est,
+                     double* out);
+
+/* MIMOChannel.apply_channel (:313-345) for caller-supplied tx [B][S][T][nsc], H [B][S][R][T][nsc]:
+ * y = Hx, noise power from the realised frame power.  n_re/n_im [B][S][R][nsc] or NULL (Philox). */
+int chest_apply_channel(chest_ctx* ctx, void* stream, int32_t num_frames, const float* tx, const float* H,
+                        const float* snr_db /*[B]*/, const float* n_re, const float* n_im,
+                        uint64_t seed, uint64_t frame_offset, float* rx);
+
+/* ChannelModel.generate_time_varying_channel (:84-127), dense public API:
+ * out [num_samples][R][T][D+1] c64 (D = max delay of the profile), u_angle/u_phase
+ * [num_paths][T][R][20] or NULL (Philox). num_tx/num_rx are arguments as in the reference. */
+int chest_time_varying_channel(chest_ctx* ctx, void* stream, int32_t channel_type, float doppler_hz,
+                               int64_t num_samples, int32_t num_tx, int32_t num_rx,
+                               const float* u_angle, const float* u_phase,
+                               uint64_t seed, uint64_t frame_index, float* out);
+
+/* OFDMSystem.modulate / demodulate (:150-203): symbols [n][nsc] c64 <-> time [n][N+cp] c64. */
+int chest_ofdm_modulate(chest_ctx* ctx, void* stream, int32_t n, const float* symbols, float* time_out);
+int chest_ofdm_demodulate(chest_ctx* ctx, void* stream, int32_t n, const float* time_in, float* symbols_out);
+
+/* equalize_channel (src/baseline_estimators.py:273-312): rx [B][S][R][nsc], H_est [B][S][R][T][nsc]
+ * -> out [B][S][T][nsc]; method 0 = 'zf' (1e-8 loading), 1 = 'mmse' (noise_var 0.01). */
+int chest_equalize(chest_ctx* ctx, void* stream, int32_t num_frames, const float* rx, const float* H_est,
+                   int32_t method, float* out);
+
+/* Full-covariance MMSE (MMSEEstimator(channel_covariance=R, estimate_statistics=False), :181-190).
+ * prepare: W = R (R + sigma^2 I)^-1 in float64 on the device (blocked Cholesky), stored as c64
+ *          W [P][P]; cov is DEVICE complex128 [P][P] (interleaved doubles).
+ * apply  : h_mmse = W h_ls for B*R*T right-hand sides on the f32 MFMA pipe, then interpolation with
+ *          the slot's plan -> H_est [B][S][R][T][nsc]. */
+int chest_mmse_full_prepare(chest_ctx* ctx, void* stream, int32_t num_pilots, const double* cov,
+                            float snr_db, float* W, double* workspace, int64_t workspace_bytes);
+int64_t chest_mmse_full_workspace_bytes(int32_t num_pilots);
+int chest_mmse_full_apply(chest_ctx* ctx, void* stream, int32_t num_frames, const float* rx4d,
+                          const float* tx_pilots, int32_t pilot_stride, int32_t pattern_slot,
+                          const float* W, float* h_scratch /*[2][B*R*T][roundup16(P)] c64*/, float* H_est);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CHEST_H_ */

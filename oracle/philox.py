@@ -1,0 +1,82 @@
+"""CPU restatement of the engine's counter-based random streams (TEST INFRASTRUCTURE ONLY).
+
+Philox4x32-10 (Salmon et al., "Parallel random numbers: as easy as 1, 2, 3", SC'11) keyed exactly as
+``csrc/chest_device.h`` does: counter = (index, stream, frame_lo, frame_hi), key = (seed_lo, seed_hi).
+``native_frame_draws`` returns the same dict of draws as ``cpu_ref.legacy_frame_draws`` so the float64
+oracle can be run on the engine's own random inputs.  This has no counterpart in the reference (which
+uses the sequential global MT19937 stream); it pins the native-RNG mode of the engine to the oracle.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+STREAM_OSC, STREAM_SYM, STREAM_NOISE = 1, 2, 3
+_M0, _M1 = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57)
+_W0, _W1 = 0x9E3779B9, 0xBB67AE85
+_MASK = np.uint64(0xFFFFFFFF)
+
+
+def philox4x32_10(c0, c1, c2, c3, k0, k1):
+    """Vectorised over ``c0`` (uint32 array); other counter words / key words are scalars."""
+    c0 = np.asarray(c0, dtype=np.uint64)
+    c1 = np.full_like(c0, c1)
+    c2 = np.full_like(c0, c2)
+    c3 = np.full_like(c0, c3)
+    k0 = int(k0) & 0xFFFFFFFF
+    k1 = int(k1) & 0xFFFFFFFF
+    for _ in range(10):
+        p0 = _M0 * c0
+        p1 = _M1 * c2
+        hi0, lo0 = p0 >> np.uint64(32), p0 & _MASK
+        hi1, lo1 = p1 >> np.uint64(32), p1 & _MASK
+        c0, c1, c2, c3 = hi1 ^ c1 ^ np.uint64(k0), lo1, hi0 ^ c3 ^ np.uint64(k1), lo0
+        k0 = (k0 + _W0) & 0xFFFFFFFF
+        k1 = (k1 + _W1) & 0xFFFFFFFF
+    return c0.astype(np.uint32), c1.astype(np.uint32), c2.astype(np.uint32), c3.astype(np.uint32)
+
+
+def draw(seed, frame, stream, index):
+    seed = int(seed) & (2**64 - 1)
+    frame = int(frame) & (2**64 - 1)
+    return philox4x32_10(np.asarray(index, dtype=np.uint64), stream, frame & 0xFFFFFFFF, frame >> 32,
+                         seed & 0xFFFFFFFF, seed >> 32)
+
+
+def u01(x):
+    """24-bit uniform in [0,1), as float32 exactly like the device, returned as float64."""
+    return (x >> np.uint32(8)).astype(np.float64) * 2.0 ** -24
+
+
+def u01_open0(x):
+    return ((x >> np.uint32(8)).astype(np.float64) + 1.0) * 2.0 ** -24
+
+
+def gauss_pair(a, b):
+    mag = np.sqrt(-2.0 * np.log(u01_open0(a)))
+    ang = 2.0 * np.pi * u01(b)
+    return mag * np.cos(ang), mag * np.sin(ang)
+
+
+def native_frame_draws(seed, frame, pilot_indices, num_symbols, num_sc, num_tx, num_rx, num_paths):
+    """The engine's draws for global frame index ``frame`` in the oracle's input format."""
+    S, nsc, T, R, L = num_symbols, num_sc, num_tx, num_rx, num_paths
+    G = S * nsc
+    sx = draw(seed, frame, STREAM_SYM, np.arange(G))[0]
+    u = u01(sx)                                            # indexed by draw slot
+    P = len(pilot_indices)
+    n_osc = L * T * R * 20
+    ox, oy, _, _ = draw(seed, frame, STREAM_OSC, np.arange(n_osc))
+    u_angle = u01(ox).reshape(L, T, R, 20)
+    u_phase = u01(oy).reshape(L, T, R, 20)
+    R2 = (R + 1) // 2
+    w = draw(seed, frame, STREAM_NOISE, np.arange(S * R2 * nsc))
+    n_re = np.empty((S, R, nsc))
+    n_im = np.empty((S, R, nsc))
+    for r in range(R):
+        a, b = (w[0], w[1]) if r % 2 == 0 else (w[2], w[3])
+        re, im = gauss_pair(a, b)
+        re = re.reshape(S, R2, nsc)[:, r // 2, :]
+        im = im.reshape(S, R2, nsc)[:, r // 2, :]
+        n_re[:, r, :], n_im[:, r, :] = re, im
+    return dict(pilot_indices=np.asarray(pilot_indices), u_pilot=u[:P], u_data=u[P:], u_angle=u_angle,
+                u_phase=u_phase, n_re=n_re, n_im=n_im)
