@@ -1,0 +1,251 @@
+"""Drop-in replacement for the reference's ``src/channel_simulator.py`` backed by the MI355X engine.
+
+Same names, call signatures, return conventions and error behaviour as the reference
+(``OFDMConfig``, ``MIMOConfig``, ``ChannelModel``, ``OFDMSystem``, ``PilotPattern``,
+``MIMOChannel``, ``simulate_transmission``).  Host code stays Python; every numeric step runs in
+hand-written HIP kernels behind ``include/chest.h``.
+
+Random numbers: like the reference, these single-frame calls consume the GLOBAL legacy
+``np.random`` stream, in the reference's draw order (shuffle -> pilot phases -> data phases ->
+per path/tx/rx 20 angles + 20 phases -> noise real block -> noise imaginary block), and inject the
+draws into the GPU kernels.  ``np.random.seed(s)`` followed by the same calls therefore reproduces the
+reference's frames (to complex64 rounding), and the global stream ends in the same state.
+The high-throughput path that draws on the device instead is ``engine.Engine.run_frames`` /
+``dataset_generator.generate_dataset_native``.
+
+Arrays come back as NumPy complex128 (the values carry complex64 precision) so that downstream
+reference code keeps working unchanged.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Dict, Tuple
+
+import numpy as np
+
+from . import engine as _engine
+
+NUM_OSCILLATORS = 20   # reference src/channel_simulator.py:100
+
+
+@dataclass
+class OFDMConfig:
+    """OFDM system configuration (reference src/channel_simulator.py:17-24)."""
+    fft_size: int = 1024
+    cp_length: int = 72
+    num_symbols: int = 14
+    useful_subcarriers: int = 600
+    subcarrier_spacing: float = 15000.0
+
+
+@dataclass
+class MIMOConfig:
+    """MIMO configuration (reference src/channel_simulator.py:27-31)."""
+    num_tx: int = 2
+    num_rx: int = 2
+
+
+def _geometry(ofdm: OFDMConfig, num_tx: int, num_rx: int, num_symbols=None) -> _engine.Geometry:
+    return _engine.Geometry(fft_size=int(ofdm.fft_size), cp_length=int(ofdm.cp_length),
+                            num_symbols=int(ofdm.num_symbols if num_symbols is None else num_symbols),
+                            useful_subcarriers=int(ofdm.useful_subcarriers),
+                            subcarrier_spacing=float(ofdm.subcarrier_spacing), num_tx=int(num_tx), num_rx=int(num_rx))
+
+
+def _np128(t):
+    return t.cpu().numpy().astype(np.complex128)
+
+
+class ChannelModel:
+    """EPA / EVA / ETU multipath fading model (reference src/channel_simulator.py:34-127)."""
+
+    # 3GPP TS 36.101 Annex B.2 (delays in seconds, powers in dB), as tabulated at :41-54
+    CHANNEL_PROFILES = {
+        'EPA': {'delays': np.array([0, 30, 70, 90, 110, 190, 410]) * 1e-9,
+                'powers': np.array([0.0, -1.0, -2.0, -3.0, -8.0, -17.2, -20.8])},
+        'EVA': {'delays': np.array([0, 30, 150, 310, 370, 710, 1090, 1730, 2510]) * 1e-9,
+                'powers': np.array([0.0, -1.5, -1.4, -3.6, -0.6, -9.1, -7.0, -12.0, -16.9])},
+        'ETU': {'delays': np.array([0, 50, 120, 200, 230, 500, 1600, 2300, 5000]) * 1e-9,
+                'powers': np.array([-1.0, -1.0, -1.0, 0.0, 0.0, 0.0, -3.0, -5.0, -7.0])},
+    }
+
+    def __init__(self, model_type: str, doppler_hz: float, carrier_freq: float, sampling_rate: float):
+        self.model_type = model_type.upper()
+        self.doppler_hz = doppler_hz
+        self.carrier_freq = carrier_freq
+        self.sampling_rate = sampling_rate
+        profile = self.CHANNEL_PROFILES[self.model_type]          # KeyError on unknown type (:72)
+        self.delays = profile['delays']
+        self.powers_db = profile['powers']
+        p = 10 ** (self.powers_db / 10)
+        self.powers_linear = p / np.sum(p)
+        self.delay_samples = np.round(self.delays * sampling_rate).astype(int)
+        self.num_paths = len(self.delays)
+
+    def _draw_oscillators(self, num_tx: int, num_rx: int):
+        """20 angles then 20 phases per (path, tx, rx), in that loop order (:102-110)."""
+        ua = np.empty((self.num_paths, num_tx, num_rx, NUM_OSCILLATORS))
+        up = np.empty_like(ua)
+        for l in range(self.num_paths):
+            for t in range(num_tx):
+                for r in range(num_rx):
+                    ua[l, t, r] = np.random.rand(NUM_OSCILLATORS)
+                    up[l, t, r] = np.random.rand(NUM_OSCILLATORS)
+        return ua, up
+
+    def _engine_for_rate(self, num_tx, num_rx):
+        # the dense kernel only needs sampling_rate = fft_size * spacing; any geometry with that product works
+        return _engine.get_engine(_engine.Geometry(fft_size=1024, cp_length=72, num_symbols=14, useful_subcarriers=600,
+                                                   subcarrier_spacing=float(self.sampling_rate) / 1024.0,
+                                                   num_tx=max(1, min(int(num_tx), 8)), num_rx=max(1, min(int(num_rx), 8))))
+
+    def generate_time_varying_channel(self, num_samples: int, num_tx: int, num_rx: int) -> np.ndarray:
+        """(num_samples, num_rx, num_tx, max_delay+1) complex Jakes channel (:84-127)."""
+        ua, up = self._draw_oscillators(num_tx, num_rx)
+        eng = self._engine_for_rate(num_tx, num_rx)
+        _, d = eng.tap_table(self.model_type)
+        if not np.array_equal(d, self.delay_samples):
+            raise NotImplementedError("custom CHANNEL_PROFILES entries are not supported by the engine")
+        h = eng.time_varying_channel(self.model_type, self.doppler_hz, num_samples, num_tx, num_rx, ua, up)
+        return _np128(h)
+
+
+class OFDMSystem:
+    """OFDM modulation / demodulation (reference src/channel_simulator.py:130-203)."""
+
+    def __init__(self, config: OFDMConfig):
+        self.config = config
+        self.sampling_rate = config.fft_size * config.subcarrier_spacing
+        self.dc_idx = config.fft_size // 2
+        idx = np.arange(self.dc_idx - config.useful_subcarriers // 2, self.dc_idx + config.useful_subcarriers // 2)
+        self.used_indices = idx[idx != self.dc_idx]
+
+    def _eng(self):
+        return _engine.get_engine(_geometry(self.config, 1, 1))
+
+    def modulate(self, symbols: np.ndarray) -> np.ndarray:
+        """(num_symbols, nsc) -> (num_symbols, fft_size + cp_length) (:150-178)."""
+        return _np128(self._eng().ofdm_modulate(np.asarray(symbols)))
+
+    def demodulate(self, received_signal: np.ndarray) -> np.ndarray:
+        """(num_symbols, fft_size + cp_length) -> (num_symbols, nsc) (:180-203)."""
+        return _np128(self._eng().ofdm_demodulate(np.asarray(received_signal)))
+
+
+class PilotPattern:
+    """Random scattered pilot pattern (reference src/channel_simulator.py:206-260).  Integer work,
+    bit-exact with the reference: consumes one ``np.random.shuffle`` of ``num_subcarriers*num_symbols``."""
+
+    def __init__(self, num_subcarriers: int, num_symbols: int, pilot_density: float = 0.1):
+        self.num_subcarriers = num_subcarriers
+        self.num_symbols = num_symbols
+        self.pilot_density = pilot_density
+        total = num_subcarriers * num_symbols
+        n_pilots = int(total * pilot_density)
+        order = np.arange(total)
+        np.random.shuffle(order)
+        self.pilot_indices = np.sort(order[:n_pilots])
+        self.pilot_positions = np.unravel_index(self.pilot_indices, (num_symbols, num_subcarriers))
+        self.pilot_mask = np.zeros((num_symbols, num_subcarriers), dtype=bool)
+        self.pilot_mask[self.pilot_positions] = True
+
+    def insert_pilots(self, data_symbols: np.ndarray, pilot_symbols: np.ndarray) -> np.ndarray:
+        grid = np.zeros((self.num_symbols, self.num_subcarriers), dtype=complex)
+        grid[self.pilot_mask] = pilot_symbols
+        grid[~self.pilot_mask] = data_symbols
+        return grid
+
+    def extract_pilots(self, grid: np.ndarray) -> np.ndarray:
+        return grid[self.pilot_mask]
+
+    def get_pilot_positions(self) -> Tuple[np.ndarray, np.ndarray]:
+        return self.pilot_positions
+
+
+class MIMOChannel:
+    """MIMO channel generation and application (reference src/channel_simulator.py:263-345)."""
+
+    def __init__(self, ofdm_config: OFDMConfig, mimo_config: MIMOConfig, channel_model: ChannelModel):
+        self.ofdm_config = ofdm_config
+        self.mimo_config = mimo_config
+        self.channel_model = channel_model
+        self.ofdm_system = OFDMSystem(ofdm_config)
+
+    def _eng(self, num_symbols):
+        return _engine.get_engine(_geometry(self.ofdm_config, self.mimo_config.num_tx, self.mimo_config.num_rx, num_symbols))
+
+    def _check_rate(self):
+        fs = self.ofdm_config.fft_size * self.ofdm_config.subcarrier_spacing
+        if abs(fs - self.channel_model.sampling_rate) > 1e-6 * fs:
+            raise NotImplementedError("channel_model.sampling_rate must equal fft_size * subcarrier_spacing")
+
+    def generate_channel_frequency_response(self, num_symbols: int) -> np.ndarray:
+        """(num_symbols, num_rx, num_tx, nsc) frequency response (:274-311)."""
+        self._check_rate()
+        cm = self.channel_model
+        ua, up = cm._draw_oscillators(self.mimo_config.num_tx, self.mimo_config.num_rx)
+        eng = self._eng(num_symbols)
+        g = eng.geom
+        slot = eng.pattern_slot(np.arange(min(4, g.grid)), None, with_plan=False)     # any pattern: H ignores it
+        d = _engine.make_descs(cm.model_type, cm.doppler_hz, 0.0, slot, n=1)
+        out = eng.run_frames(d, injected={"u_angle": ua[None], "u_phase": up[None]}, outputs=("H",))
+        return _np128(out["H"][0])
+
+    def apply_channel(self, transmitted_symbols: np.ndarray, channel_response: np.ndarray, snr_db: float) -> np.ndarray:
+        """y = Hx per RE plus AWGN scaled from the realised frame power (:313-345)."""
+        num_symbols, num_rx, num_tx, num_sc = channel_response.shape
+        if num_sc % 2 == 0:
+            raise NotImplementedError("the engine handles DC-removed grids (odd subcarrier counts) only")
+        n_re = np.random.randn(num_symbols, num_rx, num_sc)
+        n_im = np.random.randn(num_symbols, num_rx, num_sc)
+        geom = _engine.Geometry(fft_size=int(self.ofdm_config.fft_size), cp_length=int(self.ofdm_config.cp_length),
+                                num_symbols=int(num_symbols), useful_subcarriers=int(num_sc) + 1,
+                                subcarrier_spacing=float(self.ofdm_config.subcarrier_spacing), num_tx=int(num_tx),
+                                num_rx=int(num_rx))
+        eng = _engine.get_engine(geom)
+        rx = eng.apply_channel(np.asarray(transmitted_symbols), np.asarray(channel_response), snr_db, n_re[None], n_im[None])
+        return _np128(rx[0])
+
+
+def simulate_transmission(config: Dict, channel_type: str = 'EPA', doppler_hz: float = 50, snr_db: float = 10,
+                          pilot_density: float = 0.1) -> Dict:
+    """Complete MIMO-OFDM transmission simulation (reference src/channel_simulator.py:348-421).
+
+    One fused GPU launch produces tx/rx/H; the random inputs are drawn here from ``np.random`` in the
+    reference's order.  Returns the reference's 8-key dict.
+    """
+    ofdm_cfg = OFDMConfig(fft_size=config['ofdm']['fft_size'], cp_length=config['ofdm']['cp_length'],
+                          num_symbols=config['ofdm']['num_symbols'],
+                          useful_subcarriers=config['ofdm']['useful_subcarriers'],
+                          subcarrier_spacing=config['ofdm']['subcarrier_spacing'])
+    mimo_cfg = MIMOConfig(num_tx=config['mimo']['num_tx_antennas'], num_rx=config['mimo']['num_rx_antennas'])
+    sampling_rate = ofdm_cfg.fft_size * ofdm_cfg.subcarrier_spacing
+    channel_model = ChannelModel(channel_type, doppler_hz, config['channel']['carrier_freq'], sampling_rate)
+    mimo_channel = MIMOChannel(ofdm_cfg, mimo_cfg, channel_model)
+    S, T, R = ofdm_cfg.num_symbols, mimo_cfg.num_tx, mimo_cfg.num_rx
+    num_sc = len(mimo_channel.ofdm_system.used_indices)
+
+    pilot_pattern = PilotPattern(num_sc, S, pilot_density)                          # draw 1: shuffle
+    num_pilots = int(np.sum(pilot_pattern.pilot_mask))
+    u_pilot = np.random.random_sample(num_pilots)                                    # draw 2 (:395)
+    u_data = np.random.random_sample(S * num_sc - num_pilots)                        # draw 3 (:399)
+    ua, up = channel_model._draw_oscillators(T, R)                                   # draw 4 (:109-110)
+    n_re = np.random.randn(S, R, num_sc)                                             # draw 5 (:342)
+    n_im = np.random.randn(S, R, num_sc)
+
+    eng = _engine.get_engine(_geometry(ofdm_cfg, T, R))
+    slot = eng.pattern_slot(pilot_pattern.pilot_indices, None, with_plan=False)
+    descs = _engine.make_descs(channel_model.model_type, doppler_hz, snr_db, slot, n=1)
+    out = eng.run_frames(descs, injected={"u_sym": np.concatenate([u_pilot, u_data])[None], "u_angle": ua[None],
+                                          "u_phase": up[None], "n_re": n_re[None], "n_im": n_im[None]},
+                         outputs=("tx", "rx", "H", "pilot_symbols"))
+    return {
+        'tx_symbols': _np128(out["tx"][0]),
+        'rx_symbols': _np128(out["rx"][0]),
+        'channel': _np128(out["H"][0]),
+        'pilot_pattern': pilot_pattern,
+        'pilot_symbols': _np128(out["pilot_symbols"][0, :num_pilots]),
+        'ofdm_config': ofdm_cfg,
+        'mimo_config': mimo_cfg,
+        'snr_db': snr_db,
+    }

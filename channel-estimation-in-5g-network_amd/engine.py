@@ -87,6 +87,7 @@ class Engine:
         self._slots = {}          # pattern key -> slot
         self._slot_P = {}
         self._next_slot = 0
+        self.max_cached_patterns = 4096
         nsc = C.c_int32()
         N.check(N.lib().chest_get_used_indices(self._h, C.byref(nsc), None))
         assert nsc.value == geometry.num_sc
@@ -135,17 +136,26 @@ class Engine:
         return int(slot)
 
     def pattern_slot(self, pilot_idx, method="linear", with_plan=True):
-        """Slot for a pattern, uploading it (and building its plan) on first use."""
+        """Slot for a pattern, uploading it (and building its plan) on first use.  At most
+        ``max_cached_patterns`` auto-managed patterns stay resident; the least recently used slot is
+        re-used after that (single-frame drop-in calls draw a new random pattern every frame)."""
         key = interp_plan.pattern_key(pilot_idx, method if with_plan else None)
         slot = self._slots.get(key)
-        if slot is None:
-            plan = None
-            if with_plan:
-                S, nsc = self.geom.num_symbols, self.geom.num_sc
-                ps, pk = np.unravel_index(np.asarray(pilot_idx, dtype=np.int64), (S, nsc))
-                plan = interp_plan.build_plan(ps, pk, S, nsc, method)
-            slot = self.set_pattern(self._next_slot, pilot_idx, plan)
-            self._slots[key] = slot
+        if slot is not None:
+            self._slots[key] = self._slots.pop(key)           # mark most recently used
+            return slot
+        plan = None
+        if with_plan:
+            S, nsc = self.geom.num_symbols, self.geom.num_sc
+            ps, pk = np.unravel_index(np.asarray(pilot_idx, dtype=np.int64), (S, nsc))
+            plan = interp_plan.build_plan(ps, pk, S, nsc, method)
+        if len(self._slots) >= self.max_cached_patterns:
+            old_key = next(iter(self._slots))
+            slot = self._slots.pop(old_key)                   # chest_pattern_set syncs before freeing it
+        else:
+            slot = self._next_slot
+        slot = self.set_pattern(slot, pilot_idx, plan)
+        self._slots[key] = slot
         return slot
 
     def num_pilots(self, slot: int) -> int:
