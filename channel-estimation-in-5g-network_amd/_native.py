@@ -55,7 +55,8 @@ SIGNATURES = {
     "chest_pattern_set": (_i32, [_vp, _i32, _vp, _i32, _vp, _vp]),
     "chest_pattern_num_pilots": (_i32, [_vp, _i32]),
     "chest_get_status": (_i32, [_vp, C.POINTER(_i32)]),
-    "chest_frames_run": (_i32, [_vp, _vp, _i32, _vp, _u64, _u64, C.POINTER(Injected), C.POINTER(FrameOutputs)]),
+    "chest_frames_workspace_bytes": (_i64, [_vp, _i32]),
+    "chest_frames_run": (_i32, [_vp, _vp, _i32, _vp, _u64, _u64, C.POINTER(Injected), C.POINTER(FrameOutputs), _vp, _i64]),
     "chest_estimate_batch": (_i32, [_vp, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _f, _vp]),
     "chest_at_pilots": (_i32, [_vp, _vp, _i32, _vp, _vp, _i32, _f, _vp]),
     "chest_error_sums": (_i32, [_vp, _vp, _i64, _vp, _vp, _vp]),

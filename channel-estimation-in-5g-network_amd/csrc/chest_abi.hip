@@ -3,6 +3,7 @@
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <new>
@@ -66,9 +67,29 @@ static int build_tables(chest_ctx* ctx) {
             ++tp.ntaps;
         }
     }
-    const int iters = (fp.nsc + 1023) / 1024;
-    const int per = (fp.nsc + iters - 1) / iters;
-    ctx->block_threads = ((per + 63) / 64) * 64;
+    // Gram matrices Q[d][d'] = sum_k W_d[k] conj(W_d'[k]), W_d[k] = exp(-2 pi j kappa_k delay_d / N), float64 on the
+    // host: sum_k |sum_d a_d W_d[k]|^2 = sum_{d,d'} a_d conj(a_d') Q[d][d'] gives frame powers without a grid pass.
+    ctx->gram_host.assign((size_t)CHEST_NUM_PROFILES * KT * KT, make_float2(0.f, 0.f));
+    for (int ty = 0; ty < CHEST_NUM_PROFILES; ++ty) {
+        const TapProfile& tp = fp.prof[ty];
+        for (int d1 = 0; d1 < tp.ntaps; ++d1)
+            for (int d2 = 0; d2 < tp.ntaps; ++d2) {
+                double re = 0.0, im = 0.0;
+                for (int k = 0; k < fp.nsc; ++k) {
+                    const int kappa = (k < fp.half) ? (k - fp.half) : (k - fp.half + 1);
+                    const double a = -2.0 * M_PI * (double)kappa * (double)(tp.delay[d1] - tp.delay[d2]) / (double)fp.N;
+                    re += cos(a); im += sin(a);
+                }
+                ctx->gram_host[((size_t)ty * KT + d1) * KT + d2] = make_float2((float)re, (float)im);
+            }
+    }
+    // frame kernel: each wave owns 126 subcarriers (two per lane, lane 63 overlaps the next wave)
+    const int nwaves = (fp.nsc + 125) / 126;
+    ctx->block_threads = (nwaves > 16 ? 16 : nwaves) * 64;
+    if (const char* e = getenv("CHEST_BLOCK_THREADS")) {          // tuning knob for experiments
+        const int v = atoi(e);
+        if (v >= 64 && v <= 1024 && v % 64 == 0) ctx->block_threads = v;
+    }
     return CHEST_OK;
 }
 
@@ -130,6 +151,12 @@ int chest_create(const chest_config* cfg, chest_ctx** out) {
         delete ctx;
         return CHEST_EHIP;
     }
+    if (hipMalloc((void**)&ctx->d_gram, ctx->gram_host.size() * sizeof(float2)) != hipSuccess ||
+        hipMemcpy(ctx->d_gram, ctx->gram_host.data(), ctx->gram_host.size() * sizeof(float2), hipMemcpyHostToDevice) != hipSuccess) {
+        set_error("gram upload failed");
+        chest_destroy(ctx);
+        return CHEST_EHIP;
+    }
     const int N = cfg->fft_size;
     if ((N & (N - 1)) == 0) {                                    // FFT twiddles exp(-2 pi j n/N) from float64
         std::vector<float2> tw(N);
@@ -157,6 +184,7 @@ void chest_destroy(chest_ctx* ctx) {
     if (ctx->d_patterns) (void)hipFree(ctx->d_patterns);
     if (ctx->d_status) (void)hipFree(ctx->d_status);
     if (ctx->d_twiddle) (void)hipFree(ctx->d_twiddle);
+    if (ctx->d_gram) (void)hipFree(ctx->d_gram);
     delete ctx;
 }
 
@@ -209,17 +237,26 @@ int chest_pattern_set(chest_ctx* ctx, int32_t slot, const int32_t* pilot_idx, in
         }
     }
     auto up16 = [](size_t v) { return (v + 15) & ~(size_t)15; };
+    struct Rec { float w0, w1; uint32_t i01, i2v; };
+    std::vector<Rec> recs;
+    if (plan_idx) {
+        recs.resize(G);
+        for (int g = 0; g < G; ++g) {
+            const float w0 = plan_w[g], w1 = plan_w[(size_t)G + g], w2 = plan_w[2 * (size_t)G + g];
+            const uint32_t i0 = plan_idx[g], i1 = plan_idx[(size_t)G + g], i2 = plan_idx[2 * (size_t)G + g];
+            const uint32_t valid = !(w0 == 0.0f && w1 == 0.0f && w2 == 0.0f);     // NaN weights stay "valid"
+            recs[g] = Rec{w0, w1, i0 | (i1 << 16), i2 | (valid << 16)};
+        }
+    }
     const size_t o_slot = 0;
-    const size_t o_pidx = up16(o_slot + (size_t)G * 2);
-    const size_t o_pw = up16(o_pidx + (plan_idx ? (size_t)3 * G * 2 : 0));
-    const size_t o_pil = up16(o_pw + (plan_w ? (size_t)3 * G * 4 : 0));
+    const size_t o_plan = up16(o_slot + (size_t)G * 2);
+    const size_t o_pil = up16(o_plan + (plan_idx ? (size_t)G * sizeof(Rec) : 0));
     const size_t total = up16(o_pil + (size_t)P * 4);
     unsigned char* blk = nullptr;
     CHEST_HIP(hipMalloc((void**)&blk, total));
     std::vector<unsigned char> host(total, 0);
     memcpy(host.data() + o_slot, slots.data(), (size_t)G * 2);
-    if (plan_idx) memcpy(host.data() + o_pidx, plan_idx, (size_t)3 * G * 2);
-    if (plan_w) memcpy(host.data() + o_pw, plan_w, (size_t)3 * G * 4);
+    if (plan_idx) memcpy(host.data() + o_plan, recs.data(), (size_t)G * sizeof(Rec));
     memcpy(host.data() + o_pil, pilot_idx, (size_t)P * 4);
     if (hipMemcpy(blk, host.data(), total, hipMemcpyHostToDevice) != hipSuccess) {
         (void)hipFree(blk);
@@ -231,8 +268,7 @@ int chest_pattern_set(chest_ctx* ctx, int32_t slot, const int32_t* pilot_idx, in
     if (ph.block) { CHEST_HIP(hipDeviceSynchronize()); CHEST_HIP(hipFree(ph.block)); }
     ph.block = blk;
     ph.dev.slot = (const uint16_t*)(blk + o_slot);
-    ph.dev.plan_idx = plan_idx ? (const uint16_t*)(blk + o_pidx) : nullptr;
-    ph.dev.plan_w = plan_w ? (const float*)(blk + o_pw) : nullptr;
+    ph.dev.plan = plan_idx ? (const void*)(blk + o_plan) : nullptr;
     ph.dev.pilot_idx = (const int32_t*)(blk + o_pil);
     ph.dev.P = P;
     // table entries between the old size and `slot` stay zero (slot == nullptr -> "not set")
@@ -259,8 +295,14 @@ int chest_get_status(chest_ctx* ctx, int32_t* status) {
     return CHEST_OK;
 }
 
+int64_t chest_frames_workspace_bytes(chest_ctx* ctx, int32_t num_frames) {
+    if (!ctx || num_frames < 0) return 0;
+    return (int64_t)frames_workspace_bytes(ctx, num_frames);
+}
+
 int chest_frames_run(chest_ctx* ctx, void* stream, int32_t B, const chest_frame_desc* descs, uint64_t seed,
-                     uint64_t frame_offset, const chest_injected* inj, const chest_frame_outputs* out) {
+                     uint64_t frame_offset, const chest_injected* inj, const chest_frame_outputs* out,
+                     void* workspace, int64_t workspace_bytes) {
     if (!ctx || !out || (B > 0 && !descs)) { set_error("chest_frames_run: null argument"); return CHEST_EINVAL; }
     if (B < 0) { set_error("chest_frames_run: negative frame count"); return CHEST_EINVAL; }
     if (ctx->patterns.empty()) { set_error("chest_frames_run: no pilot pattern uploaded"); return CHEST_ESTATE; }
@@ -269,7 +311,7 @@ int chest_frames_run(chest_ctx* ctx, void* stream, int32_t B, const chest_frame_
         for (const auto& p : ctx->patterns) Pmax = p.dev.P > Pmax ? p.dev.P : Pmax;
         if (out->pilot_stride < Pmax) { set_error("pilot_stride %d < largest pattern %d", out->pilot_stride, Pmax); return CHEST_EINVAL; }
     }
-    return launch_frames(ctx, (hipStream_t)stream, B, descs, seed, frame_offset, inj, out);
+    return launch_frames(ctx, (hipStream_t)stream, B, descs, seed, frame_offset, inj, out, workspace, workspace_bytes);
 }
 
 int chest_estimate_batch(chest_ctx* ctx, void* stream, int32_t B, const float* rx4d, const float* tx_pilots,

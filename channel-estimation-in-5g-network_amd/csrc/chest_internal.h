@@ -10,6 +10,15 @@
 namespace chest {
 
 constexpr int KT = 9;   // max EFFECTIVE taps (distinct delays) a kernel keeps in registers; EPA 5, EVA 8, ETU 9
+constexpr int KTS = 10;  // float2 stride of one tap vector in the frame-state record (80-B, 16-B aligned rows)
+
+// Frame-state record written by taps_kernel and read (scalar loads) by frame_kernel:
+//   float scal[ST_SCAL]; float2 c[S*R*T][KTS]; float2 csum[S*R][KTS]
+constexpr int ST_SCAL = 8;
+enum { ST_NOISE_STD = 0, ST_SIGMA2 = 1, ST_SIGNAL_POWER = 2, ST_SUM_H2 = 3, ST_SUM_VAR = 4, ST_VALID = 5 };
+__host__ __device__ inline size_t frame_state_floats(int S, int R, int T) {
+    return (size_t)ST_SCAL + 2 * (size_t)KTS * ((size_t)S * R * T + (size_t)S * R);
+}
 
 // Tap profile after the delay-collision overwrite (quirk Q1, src/channel_simulator.py:125):
 // one entry per distinct delay, carrying the LAST path that rounds to it.
@@ -30,8 +39,7 @@ struct FrameParams {               // passed by value (kernarg segment -> scalar
 
 struct PatternDev {
     const uint16_t* slot;          // [G] draw slot of each RE: < P pilot ordinal, else P + data ordinal
-    const uint16_t* plan_idx;      // [3][G] or nullptr
-    const float* plan_w;           // [3][G] or nullptr
+    const void* plan;              // [G] 16-B records {w0, w1, i0|i1<<16, i2|valid<<16} or nullptr
     const int32_t* pilot_idx;      // [P]
     int32_t P;
     int32_t pad;
@@ -51,11 +59,13 @@ struct chest_ctx {
     int32_t delay_samples[CHEST_NUM_PROFILES][CHEST_MAX_PATHS];
     int32_t num_paths[CHEST_NUM_PROFILES];
     std::vector<chest::PatternHost> patterns;
+    std::vector<float2> gram_host;
     chest::PatternDev* d_patterns = nullptr;   // device mirror, capacity pattern_cap
     int32_t pattern_cap = 0;
     int32_t block_threads = 0;     // workgroup size of the per-frame kernels
     int32_t* d_status = nullptr;   // device error word (bad descriptor seen by a kernel)
-    float2* d_twiddle = nullptr;   // FFT twiddles exp(-2 pi j n/N), n < N (built lazily)
+    float2* d_twiddle = nullptr;   // FFT twiddles exp(-2 pi j n/N), n < N (power-of-two N only)
+    float2* d_gram = nullptr;      // [3][KT][KT] Gram matrices of the tap twiddles over the used bins
 };
 
 namespace chest {
@@ -71,7 +81,9 @@ void set_error(const char* fmt, ...);
 
 // launchers implemented in the kernel translation units
 int launch_frames(chest_ctx* ctx, hipStream_t st, int32_t B, const chest_frame_desc* descs, uint64_t seed,
-                  uint64_t frame_offset, const chest_injected* inj, const chest_frame_outputs* out);
+                  uint64_t frame_offset, const chest_injected* inj, const chest_frame_outputs* out, void* workspace,
+                  int64_t workspace_bytes);
+size_t frames_workspace_bytes(const chest_ctx* ctx, int64_t B);
 int launch_estimate(chest_ctx* ctx, hipStream_t st, int32_t B, const float* rx4d, const float* tx_pilots,
                     int32_t pilot_stride, int32_t slot, int32_t mmse, float snr_db, float* H_est);
 int launch_at_pilots(chest_ctx* ctx, hipStream_t st, int32_t n, const float* rx, const float* tx, int32_t mmse,

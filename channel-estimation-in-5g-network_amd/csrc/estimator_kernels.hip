@@ -6,13 +6,6 @@
 
 namespace chest {
 
-// h = y / (x + 1e-12)  (src/baseline_estimators.py:40, :110, :171)
-__device__ __forceinline__ float2 pilot_divide(float2 y, float2 x) {
-    const float2 xe = make_float2(x.x + 1e-12f, x.y);
-    const float inv = 1.0f / cabs2(xe);
-    return make_float2((y.x * xe.x + y.y * xe.y) * inv, (y.y * xe.x - y.x * xe.y) * inv);
-}
-
 // One workgroup per (frame, rx, tx) grid: gather pilots -> LDS, optional diagonal-statistics MMSE
 // shrinkage, then the plan-driven 3-point interpolation over all S*nsc resource elements.
 __global__ void __launch_bounds__(256)
@@ -49,18 +42,9 @@ estimate_kernel(int S, int R, int T, int nsc, const PatternDev* __restrict__ pat
         for (int i = tid; i < P; i += nthr) { float2 h = hp[i]; hp[i] = make_float2(alpha * h.x, alpha * h.y); }
         __syncthreads();
     }
-    const uint16_t* pi0 = pat.plan_idx;
-    const uint16_t* pi1 = pi0 + G;
-    const uint16_t* pi2 = pi1 + G;
-    const float* pw0 = pat.plan_w;
-    const float* pw1 = pw0 + G;
-    const float* pw2 = pw1 + G;
+    const PlanRec* __restrict__ plan = (const PlanRec*)pat.plan;
     for (int g = tid; g < G; g += nthr) {
-        const float2 a0 = hp[pi0[g]], a1 = hp[pi1[g]], a2 = hp[pi2[g]];
-        const float w0 = pw0[g], w1 = pw1[g], w2 = pw2[g];
-        float2 v;
-        v.x = fmaf(w2, a2.x, fmaf(w1, a1.x, w0 * a0.x));
-        v.y = fmaf(w2, a2.y, fmaf(w1, a1.y, w0 * a0.y));
+        const float2 v = interp(plan[g], hp, 1, 0);
         const int s = g / nsc, k = g - s * nsc;
         H_est[frame_base + ((size_t)(s * R + r) * T + t) * nsc + k] = v;
     }
@@ -74,7 +58,7 @@ int launch_estimate(chest_ctx* ctx, hipStream_t st, int32_t B, const float* rx4d
         return CHEST_ESTATE;
     }
     const PatternDev& pd = ctx->patterns[slot].dev;
-    if (pd.plan_idx == nullptr) { set_error("pattern slot %d has no interpolation plan", slot); return CHEST_ESTATE; }
+    if (pd.plan == nullptr) { set_error("pattern slot %d has no interpolation plan", slot); return CHEST_ESTATE; }
     const size_t lds = (size_t)pd.P * sizeof(float2) + 32 * sizeof(float);
     if (lds > 160 * 1024) { set_error("too many pilots for LDS"); return CHEST_EINVAL; }
     static thread_local size_t lds_attr = 0;

@@ -1,5 +1,4 @@
-// Fused per-frame pipeline for gfx950: one workgroup synthesises one complete OFDM-MIMO frame and
-// its LS / MMSE channel estimates entirely on chip and only WRITES to HBM.
+// Fused per-frame pipeline for gfx950.
 //
 //   reference path replaced (one iteration of src/dataset_generator.py:112-125):
 //     simulate_transmission          src/channel_simulator.py:348-421
@@ -10,116 +9,49 @@
 //     MMSEEstimator.estimate         src/baseline_estimators.py:155-196, :232-270 (Q10, diagonal statistics)
 //     evaluate_estimator sums        src/baseline_estimators.py:326-337
 //
-// Work split: thread <-> subcarrier k (grid-stride over nsc inside the workgroup), loops over symbols
-// and antennas.  Lanes of a wave write consecutive subcarriers, so every store is a fully coalesced
-// 512-B wave transaction.  The only HBM/L2 reads are the 16-B frame descriptor and the pattern's
-// slot / interpolation-plan tables (shared by all frames of a pattern group, L2-resident).
-//
-// LDS holds: oscillator table, tap coefficients c[s][r][t][d], their tx-sums, pilot LS estimates.
+// Two launches per batch:
+//   taps_kernel  (K1)  one workgroup per frame: oscillators -> tap gains c[s][r][t][d] at the symbol starts,
+//                      their tx-sums, and -- through the Gram matrix of the tap twiddles over the used bins --
+//                      the frame's realised signal power mean|y|^2 WITHOUT touching the 14x599 grid.  Writes a
+//                      ~7 KB "frame state" record (workspace).
+//   frame_kernel (K2)  one workgroup per frame, thread <-> two adjacent subcarriers: reads the record through
+//                      SCALAR loads (wave-uniform addresses -> SGPR operands of the tap FMAs), synthesises
+//                      H / tx / rx and the LS + MMSE estimates on chip and only WRITES to HBM, 16 B per lane
+//                      (1 KiB per wave store).  Its few vector loads (pilot slots, plan records) are issued one
+//                      symbol ahead of the stores so that no load waits behind HBM write latency (vmcnt is in-order).
 #include "chest_device.h"
 #include "chest_internal.h"
 
 namespace chest {
 
-struct FrameLds {
-    float2* osc;     // [nt*T*R*20]  (fd*cos(angle) [Hz], phase [turns])
-    float2* c;       // [S*R*T*nt]
-    float2* csum;    // [S*R*nt]
-    float2* hp;      // [Pmax*R]
-    float* tsl;      // [S]
-    float* amp;      // [KT]
-    int* tdelay;     // [KT]
-    int* tpath;      // [KT]
-    float* red;      // [32]
-    float* scal;     // [16]: 0 noise_std, 1 sigma2, 2.. alpha[r]
-};
-
-__host__ __device__ inline size_t frame_lds_bytes(int S, int T, int R, int Pmax) {
-    size_t n = 0;
-    n += (size_t)KT * T * R * CHEST_NUM_OSC * sizeof(float2);
-    n += (size_t)S * R * T * KT * sizeof(float2);
-    n += (size_t)S * R * KT * sizeof(float2);
-    n += (size_t)Pmax * R * sizeof(float2);
-    n += (size_t)CHEST_MAX_SYMBOLS * sizeof(float);
-    n += (size_t)KT * (sizeof(float) + 2 * sizeof(int));
-    n += 32 * sizeof(float) + 16 * sizeof(float) + 64;
-    return (n + 15) & ~(size_t)15;
-}
-
-__device__ __forceinline__ FrameLds carve(unsigned char* base, int S, int T, int R, int Pmax) {
-    FrameLds l;
-    size_t o = 0;
-    l.osc = (float2*)(base + o);  o += (size_t)KT * T * R * CHEST_NUM_OSC * sizeof(float2);
-    l.c = (float2*)(base + o);    o += (size_t)S * R * T * KT * sizeof(float2);
-    l.csum = (float2*)(base + o); o += (size_t)S * R * KT * sizeof(float2);
-    l.hp = (float2*)(base + o);   o += (size_t)Pmax * R * sizeof(float2);
-    l.tsl = (float*)(base + o);   o += (size_t)CHEST_MAX_SYMBOLS * sizeof(float);
-    l.amp = (float*)(base + o);   o += (size_t)KT * sizeof(float);
-    l.tdelay = (int*)(base + o);  o += (size_t)KT * sizeof(int);
-    l.tpath = (int*)(base + o);   o += (size_t)KT * sizeof(int);
-    l.red = (float*)(base + o);   o += 32 * sizeof(float);
-    l.scal = (float*)(base + o);
-    return l;
-}
-
-// exp(-2 pi j kappa_k d / N) for the thread's subcarrier, one per effective tap.
-__device__ __forceinline__ void twiddles(float2 (&W)[KT], int k, int nt, const int* tdelay, int half, int N) {
-    const int kappa = (k < half) ? (k - half) : (k - half + 1);
-#pragma unroll
-    for (int d = 0; d < KT; ++d) {
-        if (d < nt) {
-            int m = (kappa * tdelay[d]) % N;
-            if (m < 0) m += N;
-            float s, c;
-            sincospif(2.0f * (float)m / (float)N, &s, &c);
-            W[d] = make_float2(c, -s);
-        } else {
-            W[d] = make_float2(0.f, 0.f);
-        }
-    }
-}
-
-__device__ __forceinline__ float2 tap_dot(const float2* __restrict__ coef, const float2 (&W)[KT], int nt) {
-    float2 acc = make_float2(0.f, 0.f);
-#pragma unroll
-    for (int d = 0; d < KT; ++d)
-        if (d < nt) cfma(acc, coef[d], W[d]);
-    return acc;
-}
-
-__global__ void __launch_bounds__(1024)
-frame_kernel(const FrameParams fp, const chest_frame_desc* __restrict__ descs,
-             const PatternDev* __restrict__ patterns, int npatterns, int Pmax, uint64_t seed,
-             uint64_t frame_offset, const chest_injected inj, const chest_frame_outputs out,
-             int* __restrict__ status) {
+// ================================================================================================
+// K1: per-frame tap gains and analytic powers
+// ================================================================================================
+__global__ void __launch_bounds__(256)
+taps_kernel(const FrameParams fp, const chest_frame_desc* __restrict__ descs, int npatterns,
+            const float2* __restrict__ gram, uint64_t seed, uint64_t frame_offset,
+            const float* __restrict__ inj_angle, const float* __restrict__ inj_phase, int inj_paths,
+            float* __restrict__ state, int* __restrict__ status) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const int b = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
-    const int S = fp.S, T = fp.T, R = fp.R, nsc = fp.nsc, G = fp.G;
-    const FrameLds L = carve(lds_raw, S, T, R, Pmax);
-
+    const int S = fp.S, T = fp.T, R = fp.R;
     const chest_frame_desc fd = descs[b];
-    if ((unsigned)fd.channel_type >= CHEST_NUM_PROFILES || (unsigned)fd.pattern_slot >= (unsigned)npatterns ||
-        patterns[fd.pattern_slot].slot == nullptr) {
-        if (tid == 0) atomicExch(status, 1);
-        return;                                    // uniform for the whole workgroup
+    float* rec = state + (size_t)b * frame_state_floats(S, R, T);
+    if ((unsigned)fd.channel_type >= CHEST_NUM_PROFILES || (unsigned)fd.pattern_slot >= (unsigned)npatterns) {
+        if (tid == 0) { atomicExch(status, 1); rec[ST_VALID] = 0.f; }
+        return;
     }
-    const PatternDev pat = patterns[fd.pattern_slot];
     const TapProfile& prof = fp.prof[fd.channel_type];
-    const int nt = prof.ntaps, P = pat.P;
+    const int nt = prof.ntaps;
+    float2* osc = (float2*)lds_raw;                              // [nt*T*R*20]
+    float2* csum_l = osc + (size_t)KT * T * R * CHEST_NUM_OSC;   // [S*R*KTS]
+    float* red = (float*)(csum_l + (size_t)S * R * KTS);         // [32]
+    float2* c_g = (float2*)(rec + ST_SCAL);                      // [S*R*T][KTS]
+    float2* csum_g = c_g + (size_t)S * R * T * KTS;              // [S*R][KTS]
     const uint64_t frame = frame_offset + (uint64_t)b;
     const RngKey key{(uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)frame, (uint32_t)(frame >> 32)};
 
-    // ---- phase A0: per-frame tables into LDS -------------------------------------------------
-    if (tid < nt) { L.amp[tid] = prof.amp[tid]; L.tdelay[tid] = prof.delay[tid]; L.tpath[tid] = prof.path[tid]; }
-    if (tid < S) L.tsl[tid] = fp.ts[tid];
-    if (tid == 0) {
-        const double snr_lin = pow(10.0, (double)fd.snr_db / 10.0);
-        L.scal[1] = (float)(1.0 / snr_lin);        // MMSE sigma^2 (src/baseline_estimators.py:174-175)
-        L.scal[3] = (float)snr_lin;
-    }
-    __syncthreads();
-
-    // ---- phase A1: oscillators (src/channel_simulator.py:109-110, :119) ----------------------------
+    // ---- oscillators (src/channel_simulator.py:109-110, :119): Doppler shift [Hz] and phase [turns] ----
     const int nosc = nt * T * R * CHEST_NUM_OSC;
     for (int i = tid; i < nosc; i += nthr) {
         const int n = i % CHEST_NUM_OSC;
@@ -127,32 +59,32 @@ frame_kernel(const FrameParams fp, const chest_frame_desc* __restrict__ descs,
         const int r = q % R; q /= R;
         const int t = q % T;
         const int d = q / T;
-        const int path = L.tpath[d];
-        const int src = ((path * T + t) * R + r) * CHEST_NUM_OSC + n;
+        const int src = ((prof.path[d] * T + t) * R + r) * CHEST_NUM_OSC + n;
         float ua, up;
-        if (inj.u_angle != nullptr) {
-            const size_t base = (size_t)b * inj.inj_paths * T * R * CHEST_NUM_OSC;
-            ua = inj.u_angle[base + src];
-            up = inj.u_phase[base + src];
+        if (inj_angle != nullptr) {
+            const size_t base = (size_t)b * inj_paths * T * R * CHEST_NUM_OSC;
+            ua = inj_angle[base + src];
+            up = inj_phase[base + src];
         } else {
             const u32x4 w = draw(key, STREAM_OSC, (uint32_t)src);
             ua = u01(w.x);
             up = u01(w.y);
         }
-        L.osc[i] = make_float2(fd.doppler_hz * cospif(2.0f * ua), up);
+        osc[i] = make_float2(fd.doppler_hz * __builtin_amdgcn_cosf(__builtin_amdgcn_fractf(ua)), up);
     }
     __syncthreads();
 
-    // ---- phase A2: tap gains at the 14 symbol starts (:118-125 evaluated at :301-302) ----------------
+    // ---- tap gains at the symbol starts (:118-125 evaluated at :301-302) -> global record -------------
     const int nc = S * R * T * nt;
     for (int j = tid; j < nc; j += nthr) {
         const int d = j % nt;
-        int q = j / nt;
-        const int t = q % T; q /= T;
-        const int r = q % R;
-        const int s = q / R;
-        const float ts = L.tsl[s];
-        const float2* o = L.osc + ((d * T + t) * R + r) * CHEST_NUM_OSC;
+        int q = j / nt;                                          // (s*R + r)*T + t
+        const int t = q % T;
+        const int sr = q / T;
+        const int r = sr % R;
+        const int s = sr / R;
+        const float ts = fp.ts[s];
+        const float2* o = osc + ((d * T + t) * R + r) * CHEST_NUM_OSC;
         float2 acc = make_float2(0.f, 0.f);
 #pragma unroll 4
         for (int n = 0; n < CHEST_NUM_OSC; ++n) {
@@ -160,184 +92,438 @@ frame_kernel(const FrameParams fp, const chest_frame_desc* __restrict__ descs,
             const float2 e = cis_turns(fmaf(ab.x, ts, ab.y));
             acc.x += e.x; acc.y += e.y;
         }
-        const float a = L.amp[d];
-        L.c[j] = make_float2(a * acc.x, a * acc.y);
+        const float a = prof.amp[d];
+        c_g[(size_t)q * KTS + d] = make_float2(a * acc.x, a * acc.y);
     }
-    __syncthreads();
-    // ---- phase A3: tx-summed taps (every TX sends the same grid, quirk Q5) ------------------------
-    const int ncs = S * R * nt;
-    for (int j = tid; j < ncs; j += nthr) {
-        const int d = j % nt;
-        const int sr = j / nt;
+    // zero the padding taps so that readers may always load KTS entries
+    for (int j = tid; j < S * R * T * (KTS - nt); j += nthr) {
+        const int q = j / (KTS - nt), d = nt + j % (KTS - nt);
+        c_g[(size_t)q * KTS + d] = make_float2(0.f, 0.f);
+    }
+    __syncthreads();                                             // workgroup-scope visibility of c_g
+
+    // ---- tx-summed taps (every TX sends the same grid, quirk Q5) ----------------------------------------
+    for (int j = tid; j < S * R * KTS; j += nthr) {
+        const int d = j % KTS, sr = j / KTS;
         float2 acc = make_float2(0.f, 0.f);
-        for (int t = 0; t < T; ++t) { const float2 v = L.c[(sr * T + t) * nt + d]; acc.x += v.x; acc.y += v.y; }
-        L.csum[j] = acc;
+        for (int t = 0; t < T; ++t) { const float2 v = c_g[((size_t)sr * T + t) * KTS + d]; acc.x += v.x; acc.y += v.y; }
+        csum_l[j] = acc;
+        csum_g[j] = acc;
     }
     __syncthreads();
 
-    // ---- phase P: realised signal power mean|y|^2 (:337); |x| = 1 so |y| = |sum_t H| -----------------
-    float pw = 0.f;
-    for (int k = tid; k < nsc; k += nthr) {
-        float2 W[KT];
-        twiddles(W, k, nt, L.tdelay, fp.half, fp.N);
-        for (int sr = 0; sr < S * R; ++sr) pw += cabs2(tap_dot(L.csum + sr * nt, W, nt));
+    // ---- analytic powers: sum_k |sum_d a_d W_d[k]|^2 = sum_{d,d'} a_d conj(a_d') Q[d][d'] ----------------
+    const float2* Q = gram + (size_t)fd.channel_type * KT * KT;
+    float p_y = 0.f, p_h = 0.f;
+    for (int j = tid; j < S * R * nt * nt; j += nthr) {
+        const int d2 = j % nt, d1 = (j / nt) % nt, sr = j / (nt * nt);
+        const float2 a = csum_l[sr * KTS + d1], bq = csum_l[sr * KTS + d2], q = Q[d1 * KT + d2];
+        const float2 ab = make_float2(a.x * bq.x + a.y * bq.y, a.y * bq.x - a.x * bq.y);   // a * conj(b)
+        p_y += ab.x * q.x - ab.y * q.y;
     }
-    pw = block_sum(pw, L.red);
-    const float signal_power = pw / (float)(S * R * nsc);
-    const float noise_std = sqrtf(signal_power / L.scal[3] * 0.5f);     // (:338-340)
+    for (int j = tid; j < S * R * T * nt * nt; j += nthr) {
+        const int d2 = j % nt, d1 = (j / nt) % nt, q0 = j / (nt * nt);
+        const float2 a = c_g[(size_t)q0 * KTS + d1], bq = c_g[(size_t)q0 * KTS + d2], q = Q[d1 * KT + d2];
+        const float2 ab = make_float2(a.x * bq.x + a.y * bq.y, a.y * bq.x - a.x * bq.y);
+        p_h += ab.x * q.x - ab.y * q.y;
+    }
+    p_y = block_sum(p_y, red);
+    p_h = block_sum(p_h, red);
+    if (tid == 0) {
+        // signal power = mean|y|^2 with |x| = 1 (:337); noise_std = sqrt(P / snr / 2) (:338-340)
+        const double snr_lin = pow(10.0, (double)fd.snr_db / 10.0);
+        const double sp = (double)p_y / ((double)S * R * fp.nsc);
+        rec[ST_NOISE_STD] = (float)sqrt(sp / snr_lin * 0.5);
+        rec[ST_SIGMA2] = (float)(1.0 / snr_lin);                 // MMSE sigma^2 (src/baseline_estimators.py:174-175)
+        rec[ST_SIGNAL_POWER] = (float)sp;
+        rec[ST_SUM_H2] = p_h;                                    // sum |H|^2 over (s,r,t,k)
+        rec[ST_SUM_VAR] = p_h - p_y / (float)T;                  // sum_t |H_t - mean_t H|^2 summed over (s,r,k)
+        rec[ST_VALID] = 1.f;
+        rec[6] = 0.f; rec[7] = 0.f;
+    }
+}
+
+// ================================================================================================
+// K2: the streaming frame kernel
+// ================================================================================================
+// Thread <-> TWO adjacent subcarriers (k0 even, k1 = k0 + 1).  A wave covers 128 subcarriers starting at
+// 126*wave, i.e. consecutive waves overlap by two: lane 63 recomputes what lane 0 of the next wave owns and only
+// serves as a shuffle source.  Every output row has nsc (odd) complex64 elements, so rows alternate between
+// 16-B aligned and 8-B shifted starts ("parity").  Aligned rows are stored as float4 (k0,k1); shifted rows as
+// float4 (k1, k0+2) with k0+2 fetched from lane+1 -- every store is a 16-B, 1-KiB-per-wave transaction
+// (6.9 TB/s store ceiling instead of 4.9 TB/s for 8-B stores, tools/micro/store_pattern.hip).
+struct RowGeom {
+    int k0;           // first subcarrier of the lane (even)
+    int nsc;
+    bool storer;      // lane < 63
+    bool first;       // global wave 0, lane 0 (owns the leading single element of shifted rows)
+};
+
+__device__ __forceinline__ float2 from_next_lane(float2 v) {
+    return make_float2(__shfl_down(v.x, 1, 64), __shfl_down(v.y, 1, 64));
+}
+
+// row: 32-bit element offset of the row start inside the frame's array; par: (absolute element offset) & 1
+__device__ __forceinline__ void store_pair(float2* __restrict__ base, unsigned row, int par, const RowGeom& g,
+                                           float2 v0, float2 v1, float2 n0) {
+    if (par == 0) {
+        if (g.storer) {
+            if (g.k0 + 1 < g.nsc) *(float4*)(base + row + g.k0) = make_float4(v0.x, v0.y, v1.x, v1.y);
+            else if (g.k0 < g.nsc) base[row + g.k0] = v0;
+        }
+    } else {
+        if (g.storer) {
+            if (g.k0 + 2 < g.nsc) *(float4*)(base + row + g.k0 + 1) = make_float4(v1.x, v1.y, n0.x, n0.y);
+            else if (g.k0 + 1 < g.nsc) base[row + g.k0 + 1] = v1;
+        }
+        if (g.first) base[row] = v0;
+    }
+}
+
+template <int NT>
+__device__ __forceinline__ void twiddles2(float2 (&W0)[NT], float2 (&W1)[NT], int k0, const TapProfile& prof,
+                                          int half, int N) {
+    const int ka = (k0 < half) ? (k0 - half) : (k0 - half + 1);
+    const int kb = (k0 + 1 < half) ? (k0 + 1 - half) : (k0 + 2 - half);
+    const float invN = 1.0f / (float)N;
+#pragma unroll
+    for (int d = 0; d < NT; ++d) {
+        int ma = (ka * prof.delay[d]) % N, mb = (kb * prof.delay[d]) % N;
+        if (ma < 0) ma += N;
+        if (mb < 0) mb += N;
+        const float2 ea = cis_unit((float)ma * invN), eb = cis_unit((float)mb * invN);
+        W0[d] = make_float2(ea.x, -ea.y);
+        W1[d] = make_float2(eb.x, -eb.y);
+    }
+}
+
+// two tap sums sharing the wave-uniform coefficients (scalar loads -> SGPR operands)
+template <int NT>
+__device__ __forceinline__ void tap_dot2(const float2* __restrict__ coef, const float2 (&W0)[NT],
+                                         const float2 (&W1)[NT], float2& a0, float2& a1) {
+    a0 = make_float2(0.f, 0.f);
+    a1 = make_float2(0.f, 0.f);
+#pragma unroll
+    for (int d = 0; d < NT; ++d) {
+        const float2 c = coef[d];
+        cfma(a0, c, W0[d]);
+        cfma(a1, c, W1[d]);
+    }
+}
+
+struct FrameArgs {
+    const FrameParams* fp;
+    const PatternDev* pat;
+    const TapProfile* prof;
+    const float* rec;
+    const float2* c_g;
+    const float2* csum_g;
+    const chest_injected* inj;
+    const chest_frame_outputs* out;
+    float2* hp;
+    float* red;
+    float* alpha;
+    RngKey key;
+    int b;
+    int par_tx, par_rx, par_h;     // parity of the frame's first element in each array
+};
+
+// TT / RR: compile-time antenna counts (0 = use the runtime values)
+template <int NT, int TT, int RR>
+__device__ __forceinline__ void frame_body(const FrameArgs& A) {
+    const FrameParams& fp = *A.fp;
+    const PatternDev& pat = *A.pat;
+    const chest_injected& inj = *A.inj;
+    const chest_frame_outputs& out = *A.out;
+    const int S = fp.S, nsc = fp.nsc, G = fp.G, P = pat.P, b = A.b;
+    const int T = TT ? TT : fp.T, R = RR ? RR : fp.R;
+    constexpr int TU = (TT == 0 || TT == 1) ? 1 : 2;         // tx rows computed back to back (TT is even or 1)
+    const int R2 = (R + 1) >> 1;
+    const int tid = threadIdx.x, lane = tid & 63, nwave = blockDim.x >> 6;
+    const float noise_std = A.rec[ST_NOISE_STD];
+    float2* __restrict__ hp = A.hp;
+    float2* __restrict__ txb = out.tx ? (float2*)out.tx + (size_t)b * S * T * nsc : nullptr;
+    float2* __restrict__ rxb = out.rx ? (float2*)out.rx + (size_t)b * S * R * nsc : nullptr;
+    float2* __restrict__ Hb = out.H ? (float2*)out.H + (size_t)b * S * R * T * nsc : nullptr;
+    float2* __restrict__ Lb = out.H_ls ? (float2*)out.H_ls + (size_t)b * S * R * T * nsc : nullptr;
+    float2* __restrict__ Mb = out.H_mmse ? (float2*)out.H_mmse + (size_t)b * S * R * T * nsc : nullptr;
+    float2* __restrict__ psb = out.pilot_symbols ? (float2*)out.pilot_symbols + (size_t)b * out.pilot_stride : nullptr;
+    const float* __restrict__ usym = inj.u_sym ? inj.u_sym + (size_t)b * G : nullptr;
+    const float* __restrict__ nre = inj.n_re ? inj.n_re + (size_t)b * S * R * nsc : nullptr;
+    const float* __restrict__ nim = inj.n_im ? inj.n_im + (size_t)b * S * R * nsc : nullptr;
+    const uint16_t* __restrict__ slots = pat.slot;
+    const int nwg = (nsc + 125) / 126;                        // waves needed to cover the subcarriers
 
     // ---- phase W: H, tx, rx (+noise), LS at pilots ----------------------------------------------
-    const size_t frameHG = (size_t)b * S * R * T * nsc;
-    const int R2 = (R + 1) >> 1;
-    for (int k = tid; k < nsc; k += nthr) {
-        float2 W[KT];
-        twiddles(W, k, nt, L.tdelay, fp.half, fp.N);
+    for (int wg = tid >> 6; wg < nwg; wg += nwave) {
+        RowGeom g;
+        g.k0 = wg * 126 + 2 * lane; g.nsc = nsc; g.storer = lane < 63; g.first = (wg == 0 && lane == 0);
+        const int k0 = g.k0;
+        const bool v0ok = k0 < nsc, v1ok = k0 + 1 < nsc;
+        const int kc0 = v0ok ? k0 : nsc - 1, kc1 = v1ok ? k0 + 1 : nsc - 1;     // clamped (loads / rng only)
+        float2 W0[NT], W1[NT];
+        twiddles2<NT>(W0, W1, kc0 == k0 ? k0 : 0, *A.prof, fp.half, fp.N);
+        u32x4 sw0 = {0, 0, 0, 0}, sw1 = {0, 0, 0, 0};
+        int slot0 = slots[kc0], slot1 = slots[kc1];                              // prefetched one symbol ahead
         for (int s = 0; s < S; ++s) {
-            const int g = s * nsc + k;
-            const int slot = pat.slot[g];
-            const float u = (inj.u_sym != nullptr) ? inj.u_sym[(size_t)b * G + slot]
-                                                   : u01(draw(key, STREAM_SYM, (uint32_t)slot).x);
-            const float2 x = cis_turns(u);                                   // exp(j 2pi u) (:395,:399)
-            if (out.tx != nullptr) {
-                float2* txp = (float2*)out.tx + ((size_t)b * S + s) * T * nsc + k;
-                for (int t = 0; t < T; ++t) txp[(size_t)t * nsc] = x;
+            const int sl0 = slot0, sl1 = slot1;
+            if (s + 1 < S) { slot0 = slots[(s + 1) * nsc + kc0]; slot1 = slots[(s + 1) * nsc + kc1]; }
+            float u0, u1;
+            if (usym != nullptr) {
+                u0 = usym[sl0]; u1 = usym[sl1];
+            } else {
+                if ((s & 3) == 0) {
+                    sw0 = draw(A.key, STREAM_SYM, (uint32_t)((s >> 2) * nsc + kc0));
+                    sw1 = draw(A.key, STREAM_SYM, (uint32_t)((s >> 2) * nsc + kc1));
+                }
+                u0 = u01(word(sw0, s & 3)); u1 = u01(word(sw1, s & 3));
             }
-            const bool is_pilot = slot < P;
-            if (is_pilot && out.pilot_symbols != nullptr)
-                ((float2*)out.pilot_symbols)[(size_t)b * out.pilot_stride + slot] = x;
-            if (out.pilot_mask != nullptr) out.pilot_mask[(size_t)b * G + g] = is_pilot ? 1 : 0;
-
-            u32x4 nz = {0, 0, 0, 0};
+            const float2 x0 = cis_unit(__builtin_amdgcn_fractf(u0));            // exp(j 2pi u) (:395,:399)
+            const float2 x1 = cis_unit(__builtin_amdgcn_fractf(u1));
+            const float2 xn = from_next_lane(x0);
+            if (txb != nullptr) {
+#pragma unroll 1
+                for (int t = 0; t < T; ++t) { const unsigned row = (unsigned)((s * T + t) * nsc); store_pair(txb, row, (A.par_tx + row) & 1, g, x0, x1, xn); }
+            }
+            const bool p0 = v0ok && sl0 < P, p1 = v1ok && sl1 < P;
+            if (psb != nullptr && g.storer) {
+                if (p0) psb[sl0] = x0;
+                if (p1) psb[sl1] = x1;
+            }
+            u32x4 nz0 = {0, 0, 0, 0}, nz1 = {0, 0, 0, 0};
+#pragma unroll 1
             for (int r = 0; r < R; ++r) {
-                float2 hs = make_float2(0.f, 0.f);
-                const float2* cr = L.c + (size_t)((s * R + r) * T) * nt;
-                if (out.H != nullptr) {
-                    float2* Hp = (float2*)out.H + frameHG + ((size_t)(s * R + r) * T) * nsc + k;
-                    for (int t = 0; t < T; ++t) {
-                        const float2 h = tap_dot(cr + t * nt, W, nt);
-                        Hp[(size_t)t * nsc] = h;
-                        hs.x += h.x; hs.y += h.y;
+                {
+                    float2 hs0 = make_float2(0.f, 0.f), hs1 = make_float2(0.f, 0.f);
+                    if (Hb != nullptr) {
+#pragma unroll 1
+                        for (int tb = 0; tb < T; tb += TU) {
+#pragma unroll
+                            for (int tu = 0; tu < TU; ++tu) {
+                                const int t = tb + tu;
+                                float2 h0, h1;
+                                tap_dot2<NT>(A.c_g + ((s * R + r) * T + t) * KTS, W0, W1, h0, h1);
+                                const unsigned row = (unsigned)(((s * R + r) * T + t) * nsc);
+                                store_pair(Hb, row, (A.par_h + row) & 1, g, h0, h1, from_next_lane(h0));
+                                hs0.x += h0.x; hs0.y += h0.y; hs1.x += h1.x; hs1.y += h1.y;
+                            }
+                        }
+                    } else {
+                        tap_dot2<NT>(A.csum_g + (s * R + r) * KTS, W0, W1, hs0, hs1);
                     }
-                } else {
-                    hs = tap_dot(L.csum + (s * R + r) * nt, W, nt);
-                }
-                const float2 y = cmul(hs, x);                                  // y = sum_t H x (:330-334)
-                float2 nv;
-                if (inj.n_re != nullptr) {
-                    const size_t ni = ((size_t)b * S * R + (size_t)s * R + r) * nsc + k;
-                    nv = make_float2(inj.n_re[ni], inj.n_im[ni]);
-                } else {
-                    if ((r & 1) == 0) nz = draw(key, STREAM_NOISE, (uint32_t)((s * R2 + (r >> 1)) * nsc + k));
-                    nv = (r & 1) ? gauss_pair(nz.z, nz.w) : gauss_pair(nz.x, nz.y);
-                }
-                const float2 rxv = make_float2(fmaf(noise_std, nv.x, y.x), fmaf(noise_std, nv.y, y.y));
-                if (out.rx != nullptr) ((float2*)out.rx)[((size_t)b * S * R + (size_t)s * R + r) * nsc + k] = rxv;
-                if (is_pilot) {
-                    // h = y / (x + 1e-12)  (src/baseline_estimators.py:110)
-                    const float2 xe = make_float2(x.x + 1e-12f, x.y);
-                    const float inv = 1.0f / cabs2(xe);
-                    L.hp[slot * R + r] = make_float2((rxv.x * xe.x + rxv.y * xe.y) * inv,
-                                                     (rxv.y * xe.x - rxv.x * xe.y) * inv);
+                    const float2 y0 = cmul(hs0, x0), y1 = cmul(hs1, x1);         // y = sum_t H x (:330-334)
+                    float2 n0v, n1v;
+                    if (nre != nullptr) {
+                        const int ni = (s * R + r) * nsc;
+                        n0v = make_float2(nre[ni + kc0], nim[ni + kc0]);
+                        n1v = make_float2(nre[ni + kc1], nim[ni + kc1]);
+                    } else {
+                        if ((r & 1) == 0) {
+                            nz0 = draw(A.key, STREAM_NOISE, (uint32_t)((s * R2 + (r >> 1)) * nsc + kc0));
+                            nz1 = draw(A.key, STREAM_NOISE, (uint32_t)((s * R2 + (r >> 1)) * nsc + kc1));
+                        }
+                        n0v = (r & 1) ? gauss_pair(nz0.z, nz0.w) : gauss_pair(nz0.x, nz0.y);
+                        n1v = (r & 1) ? gauss_pair(nz1.z, nz1.w) : gauss_pair(nz1.x, nz1.y);
+                    }
+                    const float2 r0 = make_float2(fmaf(noise_std, n0v.x, y0.x), fmaf(noise_std, n0v.y, y0.y));
+                    const float2 r1 = make_float2(fmaf(noise_std, n1v.x, y1.x), fmaf(noise_std, n1v.y, y1.y));
+                    if (rxb != nullptr) {
+                        const unsigned row = (unsigned)((s * R + r) * nsc);
+                        store_pair(rxb, row, (A.par_rx + row) & 1, g, r0, r1, from_next_lane(r0));
+                    }
+                    if (g.storer) {                                              // (src/baseline_estimators.py:110)
+                        if (p0) hp[sl0 * R + r] = pilot_divide(r0, x0);
+                        if (p1) hp[sl1 * R + r] = pilot_divide(r1, x1);
+                    }
                 }
             }
         }
     }
+    const bool want_metrics = out.metrics != nullptr;
+    const bool want_est = (Lb != nullptr) || (Mb != nullptr) || want_metrics;
+    if (!want_est) return;
     __syncthreads();
-
-    const bool want_est = (out.H_ls != nullptr) || (out.H_mmse != nullptr) || (out.metrics != nullptr);
-    if (!want_est || pat.plan_idx == nullptr) {
-        if (out.metrics != nullptr && tid < CHEST_NUM_METRICS) {
-            float v = 0.f;
-            if (tid == CHEST_M_SIGNAL_POWER) v = signal_power;
-            if (tid == CHEST_M_NOISE_STD) v = noise_std;
-            if (tid == CHEST_M_COUNT) v = (float)(S * R * T) * (float)nsc;
-            out.metrics[(size_t)b * CHEST_NUM_METRICS + tid] = v;
-        }
-        if (want_est && pat.plan_idx == nullptr && tid == 0) atomicExch(status, 2);
-        return;
-    }
 
     // ---- MMSE shrinkage per rx: p = mean|h_ls|^2, alpha = p/(p+sigma^2) (:177-190, scalar form) ---
     for (int r = 0; r < R; ++r) {
         float a = 0.f;
-        for (int i = tid; i < P; i += nthr) a += cabs2(L.hp[i * R + r]);
-        a = block_sum(a, L.red);
+        for (int i = tid; i < P; i += blockDim.x) a += cabs2(hp[i * R + r]);
+        a = block_sum(a, A.red);
         if (tid == 0) {
             const double p = (double)a / (double)P;
-            L.scal[4 + r] = (float)(p / (p + (double)L.scal[1]));
+            A.alpha[r] = (float)(p / (p + (double)A.rec[ST_SIGMA2]));
         }
     }
     __syncthreads();
 
     // ---- phase E: plan-driven interpolation (griddata linear/nearest as a 3-point gather), ----------
     //      tx-broadcast stores (quirk Q9), optional error sums.
-    const uint16_t* pi0 = pat.plan_idx;
-    const uint16_t* pi1 = pat.plan_idx + G;
-    const uint16_t* pi2 = pat.plan_idx + 2 * (size_t)G;
-    const float* pw0 = pat.plan_w;
-    const float* pw1 = pat.plan_w + G;
-    const float* pw2 = pat.plan_w + 2 * (size_t)G;
-    const bool want_metrics = out.metrics != nullptr;
-    float m_h2 = 0.f, m_ls = 0.f, m_mm = 0.f;
-    for (int k = tid; k < nsc; k += nthr) {
-        float2 W[KT];
-        if (want_metrics) twiddles(W, k, nt, L.tdelay, fp.half, fp.N);
+    const PlanRec* __restrict__ plan = (const PlanRec*)pat.plan;
+    const float invT = 1.0f / (float)T;
+    float m_ls = 0.f, m_mm = 0.f;
+    for (int wg = tid >> 6; wg < nwg; wg += nwave) {
+        RowGeom g;
+        g.k0 = wg * 126 + 2 * lane; g.nsc = nsc; g.storer = lane < 63; g.first = (wg == 0 && lane == 0);
+        const int k0 = g.k0;
+        const bool v0ok = k0 < nsc, v1ok = k0 + 1 < nsc;
+        const int kc0 = v0ok ? k0 : nsc - 1, kc1 = v1ok ? k0 + 1 : nsc - 1;
+        float2 W0[NT], W1[NT];
+        if (want_metrics) twiddles2<NT>(W0, W1, kc0 == k0 ? k0 : 0, *A.prof, fp.half, fp.N);
+        PlanRec q0 = plan[kc0], q1 = plan[kc1];                                   // prefetched one symbol ahead
         for (int s = 0; s < S; ++s) {
-            const int g = s * nsc + k;
-            const int i0 = pi0[g], i1 = pi1[g], i2 = pi2[g];
-            const float w0 = pw0[g], w1 = pw1[g], w2 = pw2[g];
+            const PlanRec c0 = q0, c1 = q1;
+            if (s + 1 < S) { q0 = plan[(s + 1) * nsc + kc0]; q1 = plan[(s + 1) * nsc + kc1]; }
+#pragma unroll 1
             for (int r = 0; r < R; ++r) {
-                const float2 a0 = L.hp[i0 * R + r], a1 = L.hp[i1 * R + r], a2 = L.hp[i2 * R + r];
-                float2 v;
-                v.x = fmaf(w2, a2.x, fmaf(w1, a1.x, w0 * a0.x));
-                v.y = fmaf(w2, a2.y, fmaf(w1, a1.y, w0 * a0.y));
-                const float al = L.scal[4 + r];
-                const float2 vm = make_float2(al * v.x, al * v.y);
-                const size_t o = frameHG + ((size_t)(s * R + r) * T) * nsc + k;
-                if (out.H_ls != nullptr)
-                    for (int t = 0; t < T; ++t) ((float2*)out.H_ls)[o + (size_t)t * nsc] = v;
-                if (out.H_mmse != nullptr)
-                    for (int t = 0; t < T; ++t) ((float2*)out.H_mmse)[o + (size_t)t * nsc] = vm;
-                if (want_metrics) {
-                    const float2* cr = L.c + (size_t)((s * R + r) * T) * nt;
+                {
+                    const float2 e0 = interp(c0, hp, R, r), e1 = interp(c1, hp, R, r);
+                    const float2 en = from_next_lane(e0);
+                    const float al = A.alpha[r];
+                    const float2 f0 = make_float2(al * e0.x, al * e0.y), f1 = make_float2(al * e1.x, al * e1.y);
+                    const float2 fn = make_float2(al * en.x, al * en.y);
+#pragma unroll 1
                     for (int t = 0; t < T; ++t) {
-                        const float2 h = tap_dot(cr + t * nt, W, nt);
-                        m_h2 += cabs2(h);
-                        m_ls += cabs2(make_float2(h.x - v.x, h.y - v.y));
-                        m_mm += cabs2(make_float2(h.x - vm.x, h.y - vm.y));
+                        const unsigned row = (unsigned)(((s * R + r) * T + t) * nsc);
+                        const int par = (A.par_h + row) & 1;
+                        if (Lb != nullptr) store_pair(Lb, row, par, g, e0, e1, en);
+                        if (Mb != nullptr) store_pair(Mb, row, par, g, f0, f1, fn);
+                    }
+                    if (want_metrics) {
+                        // sum_t |H_t - v|^2 = sum_t |H_t - Hbar|^2 + T |Hbar - v|^2 ; the first term is
+                        // estimate-independent and comes analytically from K1 (ST_SUM_VAR).
+                        float2 hb0, hb1;
+                        tap_dot2<NT>(A.csum_g + (s * R + r) * KTS, W0, W1, hb0, hb1);
+                        if (g.storer && v0ok) {
+                            const float2 m = make_float2(hb0.x * invT, hb0.y * invT);
+                            m_ls += cabs2(make_float2(m.x - e0.x, m.y - e0.y));
+                            m_mm += cabs2(make_float2(m.x - f0.x, m.y - f0.y));
+                        }
+                        if (g.storer && v1ok) {
+                            const float2 m = make_float2(hb1.x * invT, hb1.y * invT);
+                            m_ls += cabs2(make_float2(m.x - e1.x, m.y - e1.y));
+                            m_mm += cabs2(make_float2(m.x - f1.x, m.y - f1.y));
+                        }
                     }
                 }
             }
         }
     }
     if (want_metrics) {
-        m_h2 = block_sum(m_h2, L.red);
-        m_ls = block_sum(m_ls, L.red);
-        m_mm = block_sum(m_mm, L.red);
+        m_ls = block_sum(m_ls, A.red);
+        m_mm = block_sum(m_mm, A.red);
         if (tid == 0) {
             float* m = out.metrics + (size_t)b * CHEST_NUM_METRICS;
-            m[CHEST_M_SUM_H2] = m_h2; m[CHEST_M_SUM_ERR_LS] = m_ls; m[CHEST_M_SUM_ERR_MMSE] = m_mm;
-            m[CHEST_M_SIGNAL_POWER] = signal_power; m[CHEST_M_NOISE_STD] = noise_std;
-            m[CHEST_M_ALPHA0] = L.scal[4]; m[CHEST_M_COUNT] = (float)(S * R * T) * (float)nsc;
+            m[CHEST_M_SUM_H2] = A.rec[ST_SUM_H2];
+            m[CHEST_M_SUM_ERR_LS] = A.rec[ST_SUM_VAR] + (float)T * m_ls;
+            m[CHEST_M_SUM_ERR_MMSE] = A.rec[ST_SUM_VAR] + (float)T * m_mm;
+            m[CHEST_M_SIGNAL_POWER] = A.rec[ST_SIGNAL_POWER]; m[CHEST_M_NOISE_STD] = noise_std;
+            m[CHEST_M_ALPHA0] = A.alpha[0]; m[CHEST_M_COUNT] = (float)(S * R * T) * (float)nsc;
             m[CHEST_M_RESERVED] = 0.f;
         }
     }
 }
 
+template <int TT, int RR>
+__global__ void __launch_bounds__(1024)
+frame_kernel(const FrameParams fp, const chest_frame_desc* __restrict__ descs,
+             const PatternDev* __restrict__ patterns, int Pmax, uint64_t seed, uint64_t frame_offset,
+             const chest_injected inj, const chest_frame_outputs out, const float* __restrict__ state,
+             int* __restrict__ status) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int S = fp.S, T = fp.T, R = fp.R, nsc = fp.nsc, G = fp.G;
+    const float* rec = state + (size_t)b * frame_state_floats(S, R, T);
+    const chest_frame_desc fd = descs[b];
+    if (rec[ST_VALID] == 0.f) return;                            // K1 flagged the descriptor (uniform exit)
+    const PatternDev pat = patterns[fd.pattern_slot];
+    if (pat.slot == nullptr) { if (tid == 0) atomicExch(status, 1); return; }
+    const bool want_est = out.H_ls != nullptr || out.H_mmse != nullptr || out.metrics != nullptr;
+    if (want_est && pat.plan == nullptr) { if (tid == 0) atomicExch(status, 2); return; }
+    const int P = pat.P;
+
+    // ---- pilot mask: 4 resource elements per thread, one 32-bit store ---------------------------------
+    if (out.pilot_mask != nullptr) {
+        uint8_t* mrow = out.pilot_mask + (size_t)b * G;
+        if ((((size_t)b * G) & 3) == 0) {
+            for (int g4 = tid * 4; g4 < G; g4 += blockDim.x * 4) {
+                if (g4 + 3 < G) {
+                    uint32_t v = 0;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v |= (pat.slot[g4 + j] < P ? 1u : 0u) << (8 * j);
+                    *(uint32_t*)(mrow + g4) = v;
+                } else {
+                    for (int g = g4; g < G; ++g) mrow[g] = pat.slot[g] < P ? 1 : 0;
+                }
+            }
+        } else {
+            for (int g = tid; g < G; g += blockDim.x) mrow[g] = pat.slot[g] < P ? 1 : 0;
+        }
+    }
+
+    FrameArgs A;
+    A.fp = &fp; A.pat = &pat; A.prof = &fp.prof[fd.channel_type]; A.rec = rec;
+    A.c_g = (const float2*)(rec + ST_SCAL);
+    A.csum_g = A.c_g + (size_t)S * R * T * KTS;
+    A.inj = &inj; A.out = &out;
+    A.hp = (float2*)lds_raw;                                     // [Pmax*R] LS estimates at the pilots
+    A.red = (float*)(A.hp + (size_t)Pmax * R);                   // [32]
+    A.alpha = A.red + 32;                                        // [8]
+    const uint64_t frame = frame_offset + (uint64_t)b;
+    A.key = RngKey{(uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)frame, (uint32_t)(frame >> 32)};
+    A.b = b;
+    A.par_tx = (int)(((size_t)b * S * T * nsc) & 1);
+    A.par_rx = (int)(((size_t)b * S * R * nsc) & 1);
+    A.par_h = (int)(((size_t)b * S * R * T * nsc) & 1);
+    switch (A.prof->ntaps) {                                     // workgroup-uniform dispatch on the profile
+        case 5: frame_body<5, TT, RR>(A); break;                 // EPA at 15.36 MHz
+        case 8: frame_body<8, TT, RR>(A); break;                 // EVA
+        default: frame_body<KT, TT, RR>(A); break;               // ETU / anything else (taps padded with zeros)
+    }
+}
+
+size_t frames_workspace_bytes(const chest_ctx* ctx, int64_t B) {
+    return (size_t)B * frame_state_floats(ctx->fp.S, ctx->fp.R, ctx->fp.T) * sizeof(float);
+}
+
+template <int TT, int RR>
+static int launch_k2(chest_ctx* ctx, hipStream_t st, int32_t B, size_t lds2, const chest_frame_desc* descs, int Pmax,
+                     uint64_t seed, uint64_t frame_offset, const chest_injected& inj, const chest_frame_outputs& out,
+                     const float* workspace) {
+    static thread_local size_t attr = 0;
+    if (lds2 > 64 * 1024 && lds2 > attr) {
+        CHEST_HIP(hipFuncSetAttribute((const void*)frame_kernel<TT, RR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+        attr = lds2;
+    }
+    hipLaunchKernelGGL((frame_kernel<TT, RR>), dim3(B), dim3(ctx->block_threads), lds2, st, ctx->fp, descs, ctx->d_patterns,
+                       Pmax, seed, frame_offset, inj, out, workspace, ctx->d_status);
+    return CHEST_OK;
+}
+
 int launch_frames(chest_ctx* ctx, hipStream_t st, int32_t B, const chest_frame_desc* descs, uint64_t seed,
-                  uint64_t frame_offset, const chest_injected* inj, const chest_frame_outputs* out) {
+                  uint64_t frame_offset, const chest_injected* inj, const chest_frame_outputs* out,
+                  void* workspace, int64_t workspace_bytes) {
     if (B <= 0) return CHEST_OK;
-    int Pmax = 1;
-    for (const auto& p : ctx->patterns) Pmax = p.dev.P > Pmax ? p.dev.P : Pmax;
-    const size_t lds = frame_lds_bytes(ctx->fp.S, ctx->fp.T, ctx->fp.R, Pmax);
-    if (lds > 160 * 1024) {
-        set_error("frame kernel needs %zu B of LDS (> 160 KiB): too many pilots/antennas", lds);
+    const FrameParams& fp = ctx->fp;
+    if (workspace == nullptr || (size_t)workspace_bytes < frames_workspace_bytes(ctx, B)) {
+        set_error("chest_frames_run: workspace of %lld B is smaller than the %zu B needed for %d frames",
+                  (long long)workspace_bytes, frames_workspace_bytes(ctx, B), B);
         return CHEST_EINVAL;
     }
-    static thread_local size_t lds_attr = 0;
-    if (lds > 64 * 1024 && lds > lds_attr) {
-        CHEST_HIP(hipFuncSetAttribute((const void*)frame_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        lds_attr = lds;
+    const void* ptrs[] = {out->tx, out->rx, out->H, out->H_ls, out->H_mmse, out->pilot_symbols, workspace};
+    for (const void* q : ptrs)
+        if (((uintptr_t)q & 15) != 0) { set_error("chest_frames_run: output/workspace pointers must be 16-byte aligned"); return CHEST_EINVAL; }
+    int Pmax = 1;
+    for (const auto& p : ctx->patterns) Pmax = p.dev.P > Pmax ? p.dev.P : Pmax;
+    const size_t lds1 = ((size_t)KT * fp.T * fp.R * CHEST_NUM_OSC + (size_t)fp.S * fp.R * KTS) * sizeof(float2) + 32 * sizeof(float);
+    const size_t lds2 = (size_t)Pmax * fp.R * sizeof(float2) + 40 * sizeof(float);
+    if (lds1 > 160 * 1024 || lds2 > 160 * 1024) {
+        set_error("frame pipeline needs %zu / %zu B of LDS (> 160 KiB): too many antennas or pilots", lds1, lds2);
+        return CHEST_EINVAL;
+    }
+    static thread_local size_t attr1 = 0;
+    if (lds1 > 64 * 1024 && lds1 > attr1) {
+        CHEST_HIP(hipFuncSetAttribute((const void*)taps_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
+        attr1 = lds1;
     }
     chest_injected inj_v{};
     if (inj != nullptr) inj_v = *inj;
@@ -345,8 +531,14 @@ int launch_frames(chest_ctx* ctx, hipStream_t st, int32_t B, const chest_frame_d
         set_error("injected u_angle/u_phase and n_re/n_im must be given in pairs");
         return CHEST_EINVAL;
     }
-    hipLaunchKernelGGL(frame_kernel, dim3(B), dim3(ctx->block_threads), lds, st, ctx->fp, descs, ctx->d_patterns,
-                       (int)ctx->patterns.size(), Pmax, seed, frame_offset, inj_v, *out, ctx->d_status);
+    hipLaunchKernelGGL(taps_kernel, dim3(B), dim3(256), lds1, st, fp, descs, (int)ctx->patterns.size(), ctx->d_gram, seed,
+                       frame_offset, inj_v.u_angle, inj_v.u_phase, inj_v.inj_paths, (float*)workspace, ctx->d_status);
+    int rc;
+    if (fp.T == 1 && fp.R == 1) rc = launch_k2<1, 1>(ctx, st, B, lds2, descs, Pmax, seed, frame_offset, inj_v, *out, (const float*)workspace);
+    else if (fp.T == 2 && fp.R == 2) rc = launch_k2<2, 2>(ctx, st, B, lds2, descs, Pmax, seed, frame_offset, inj_v, *out, (const float*)workspace);
+    else if (fp.T == 4 && fp.R == 4) rc = launch_k2<4, 4>(ctx, st, B, lds2, descs, Pmax, seed, frame_offset, inj_v, *out, (const float*)workspace);
+    else rc = launch_k2<0, 0>(ctx, st, B, lds2, descs, Pmax, seed, frame_offset, inj_v, *out, (const float*)workspace);
+    if (rc != CHEST_OK) return rc;
     CHEST_HIP(hipGetLastError());
     return CHEST_OK;
 }

@@ -150,15 +150,10 @@ interp_from_pilots_kernel(int S, int R, int T, int nsc, int Ppad, const PatternD
     const int t = m % T, r = (m / T) % R, b = m / (T * R);
     for (int i = threadIdx.x; i < P; i += blockDim.x) hp[i] = h[(size_t)m * Ppad + i];
     __syncthreads();
-    const uint16_t *pi0 = pat.plan_idx, *pi1 = pi0 + G, *pi2 = pi1 + G;
-    const float *pw0 = pat.plan_w, *pw1 = pw0 + G, *pw2 = pw1 + G;
+    const PlanRec* __restrict__ plan = (const PlanRec*)pat.plan;
     const size_t frame_base = (size_t)b * S * R * T * nsc;
     for (int g = threadIdx.x; g < G; g += blockDim.x) {
-        const float2 a0 = hp[pi0[g]], a1 = hp[pi1[g]], a2 = hp[pi2[g]];
-        const float w0 = pw0[g], w1 = pw1[g], w2 = pw2[g];
-        float2 v;
-        v.x = fmaf(w2, a2.x, fmaf(w1, a1.x, w0 * a0.x));
-        v.y = fmaf(w2, a2.y, fmaf(w1, a1.y, w0 * a0.y));
+        const float2 v = interp(plan[g], hp, 1, 0);
         const int s = g / nsc, k = g - s * nsc;
         H_est[frame_base + ((size_t)(s * R + r) * T + t) * nsc + k] = v;
     }
@@ -210,7 +205,7 @@ int chest_mmse_full_apply(chest_ctx* ctx, void* stream, int32_t B, const float* 
     }
     if (B == 0) return CHEST_OK;
     if (slot < 0 || slot >= (int)ctx->patterns.size() || ctx->patterns[slot].dev.slot == nullptr ||
-        ctx->patterns[slot].dev.plan_idx == nullptr) {
+        ctx->patterns[slot].dev.plan == nullptr) {
         set_error("pattern slot %d is not set or has no plan", slot);
         return CHEST_ESTATE;
     }

@@ -88,6 +88,7 @@ class Engine:
         self._slot_P = {}
         self._next_slot = 0
         self.max_cached_patterns = 4096
+        self._workspace = None
         nsc = C.c_int32()
         N.check(N.lib().chest_get_used_indices(self._h, C.byref(nsc), None))
         assert nsc.value == geometry.num_sc
@@ -239,8 +240,12 @@ class Engine:
                 if name in ("n_re", "n_im") and tuple(t.shape) != (B, S, R, nsc):
                     raise ValueError("n_re/n_im must be [B, S, R, nsc]")
             inj_p = C.byref(inj)
+        need = N.lib().chest_frames_workspace_bytes(self._h, B)
+        if self._workspace is None or self._workspace.numel() < need:
+            self._workspace = torch.empty(need, dtype=torch.uint8, device=self.device)
         N.check(N.lib().chest_frames_run(self._h, self._stream(), B, d_dev.data_ptr(), int(seed) & (2**64 - 1),
-                                         int(frame_offset), inj_p, C.byref(fo)), "chest_frames_run")
+                                         int(frame_offset), inj_p, C.byref(fo), self._workspace.data_ptr(),
+                                         self._workspace.numel()), "chest_frames_run")
         if check:
             self.check_status()       # synchronises; pass check=False inside timed loops
         return res

@@ -140,10 +140,13 @@ int chest_get_status(chest_ctx* ctx, int32_t* status);
  * evaluate_estimator partial sums (:326-337), i.e. the loop body of
  * ChannelEstimationDataset.generate_sample (src/dataset_generator.py:34-89), for `num_frames`
  * independent frames.  descs: DEVICE chest_frame_desc[num_frames].  Frame b uses random streams
- * keyed by (seed, frame_offset + b), so any sharding of a frame range gives identical frames. */
+ * keyed by (seed, frame_offset + b), so any sharding of a frame range gives identical frames.
+ * workspace: DEVICE scratch of chest_frames_workspace_bytes(ctx, num_frames) bytes (per-frame tap gains
+ * handed from the taps kernel to the streaming kernel; ~7 KB per 2x2 frame). */
+int64_t chest_frames_workspace_bytes(chest_ctx* ctx, int32_t num_frames);
 int chest_frames_run(chest_ctx* ctx, void* stream, int32_t num_frames, const chest_frame_desc* descs,
                      uint64_t seed, uint64_t frame_offset, const chest_injected* inj,
-                     const chest_frame_outputs* out);
+                     const chest_frame_outputs* out, void* workspace, int64_t workspace_bytes);
 
 /* LSEstimator.estimate / MMSEEstimator.estimate on caller-supplied grids (any rx_4d, not only the
  * tx-repeated one): rx4d [B][S][R][T][nsc] c64, tx_pilots [B][pilot_stride] c64 (pilot_stride 0 =

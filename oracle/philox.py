@@ -61,9 +61,13 @@ def native_frame_draws(seed, frame, pilot_indices, num_symbols, num_sc, num_tx, 
     """The engine's draws for global frame index ``frame`` in the oracle's input format."""
     S, nsc, T, R, L = num_symbols, num_sc, num_tx, num_rx, num_paths
     G = S * nsc
-    sx = draw(seed, frame, STREAM_SYM, np.arange(G))[0]
-    u = u01(sx)                                            # indexed by draw slot
-    P = len(pilot_indices)
+    # symbol phase of RE (s, k): word (s & 3) of draw(index = (s >> 2)*nsc + k)
+    S4 = (S + 3) // 4
+    sw = draw(seed, frame, STREAM_SYM, np.arange(S4 * nsc))
+    u_re = np.stack([u01(w).reshape(S4, nsc) for w in sw], axis=1).reshape(S4 * 4, nsc)[:S]
+    mask = np.zeros(G, dtype=bool)
+    mask[np.asarray(pilot_indices)] = True
+    u_flat = u_re.reshape(-1)
     n_osc = L * T * R * 20
     ox, oy, _, _ = draw(seed, frame, STREAM_OSC, np.arange(n_osc))
     u_angle = u01(ox).reshape(L, T, R, 20)
@@ -78,5 +82,5 @@ def native_frame_draws(seed, frame, pilot_indices, num_symbols, num_sc, num_tx, 
         re = re.reshape(S, R2, nsc)[:, r // 2, :]
         im = im.reshape(S, R2, nsc)[:, r // 2, :]
         n_re[:, r, :], n_im[:, r, :] = re, im
-    return dict(pilot_indices=np.asarray(pilot_indices), u_pilot=u[:P], u_data=u[P:], u_angle=u_angle,
+    return dict(pilot_indices=np.asarray(pilot_indices), u_pilot=u_flat[mask], u_data=u_flat[~mask], u_angle=u_angle,
                 u_phase=u_phase, n_re=n_re, n_im=n_im)

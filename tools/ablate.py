@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""Time the fused frame kernel with different output subsets (phase ablation by skipping stores /
+phases).  GPU only.  python tools/ablate.py [--frames 10000]"""
+import argparse
+import importlib
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+E = importlib.import_module("channel-estimation-in-5g-network_amd.engine")
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--frames", type=int, default=10000)
+ap.add_argument("--T", type=int, default=2)
+ap.add_argument("--R", type=int, default=2)
+ap.add_argument("--channel", default="EVA")
+args = ap.parse_args()
+geom = E.Geometry(num_tx=args.T, num_rx=args.R)
+eng = E.Engine(geom, 0)
+G = geom.grid
+F = args.frames
+slots = []
+for g in range((F + 1023) // 1024):
+    rs = np.random.RandomState(g)
+    slots.append(eng.pattern_slot(np.sort(rs.permutation(G)[: G // 10]), "linear"))
+d = E.make_descs(args.channel, 111.1, 10.0, np.asarray(slots, dtype=np.int32)[np.arange(F) // 1024], n=F)
+d_dev = torch.from_numpy(d.view(np.uint8).copy()).to(eng.device)
+ALL = ("tx", "rx", "H", "H_ls", "H_mmse", "pilot_symbols", "pilot_mask", "metrics")
+cases = {
+    "all+metrics": ALL,
+    "all": ALL[:-1],
+    "sim only (tx,rx,H)": ("tx", "rx", "H"),
+    "H only": ("H",),
+    "rx only": ("rx",),
+    "tx only": ("tx",),
+    "est only (H_ls,H_mmse)": ("H_ls", "H_mmse"),
+    "H_ls only": ("H_ls",),
+    "metrics only": ("metrics",),
+}
+full = eng.run_frames(d_dev, outputs=ALL)
+for name, outs in cases.items():
+    out = {k: full[k] for k in outs}
+    for _ in range(2):
+        eng.run_frames(d_dev, outputs=outs, out=out, check=False)
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(5):
+        eng.run_frames(d_dev, outputs=outs, out=out, check=False)
+    b.record()
+    torch.cuda.synchronize()
+    ms = a.elapsed_time(b) / 5
+    print(f"{name:28s} {ms:8.3f} ms   {F / ms / 1e3:8.3f} M frames/s", flush=True)
