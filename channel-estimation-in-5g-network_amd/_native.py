@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libchest.so")
+LIB_PATH = os.environ.get("CHEST_LIB") or os.path.join(_HERE, "libchest.so")   # CHEST_LIB: A/B builds only
 
 MAX_PATHS = 16
 NUM_OSC = 20

@@ -83,8 +83,8 @@ static int build_tables(chest_ctx* ctx) {
                 ctx->gram_host[((size_t)ty * KT + d1) * KT + d2] = make_float2((float)re, (float)im);
             }
     }
-    // frame kernel: each wave owns 126 subcarriers (two per lane, lane 63 overlaps the next wave)
-    const int nwaves = (fp.nsc + 125) / 126;
+    // frame kernel: wave <-> OFDM symbol; two symbols per wave measured best on MI355X (7 waves for S = 14)
+    const int nwaves = (fp.S + 1) / 2;
     ctx->block_threads = (nwaves > 16 ? 16 : nwaves) * 64;
     if (const char* e = getenv("CHEST_BLOCK_THREADS")) {          // tuning knob for experiments
         const int v = atoi(e);

@@ -11,8 +11,8 @@ namespace chest {
 // ---- random streams --------------------------------------------------------------------------
 // counter = (index, stream, frame_lo, frame_hi), key = (seed_lo, seed_hi).  oracle/philox.py mirrors this.
 //   STREAM_OSC   index = ((path*T + tx)*R + rx)*20 + n      word x -> angle uniform, y -> phase uniform
-//   STREAM_SYM   index = (s>>2)*nsc + k                     word (s&3) -> symbol phase uniform of RE (s,k)
-//   STREAM_NOISE index = (s*ceil(R/2) + (r>>1))*nsc + k     words (x,y) -> rx r even, (z,w) -> rx r odd
+//   STREAM_SYM   index = s*npair + (k>>1)                   word (k&1) -> symbol phase uniform of RE (s,k)
+//   STREAM_NOISE index = (s*R + r)*npair + (k>>1)           words (x,y) -> k even, (z,w) -> k odd   (npair = ceil(nsc/2))
 enum : uint32_t { STREAM_OSC = 1, STREAM_SYM = 2, STREAM_NOISE = 3 };
 
 struct u32x4 { uint32_t x, y, z, w; };

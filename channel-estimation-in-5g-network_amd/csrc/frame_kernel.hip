@@ -14,11 +14,12 @@
 //                      their tx-sums, and -- through the Gram matrix of the tap twiddles over the used bins --
 //                      the frame's realised signal power mean|y|^2 WITHOUT touching the 14x599 grid.  Writes a
 //                      ~7 KB "frame state" record (workspace).
-//   frame_kernel (K2)  one workgroup per frame, thread <-> two adjacent subcarriers: reads the record through
-//                      SCALAR loads (wave-uniform addresses -> SGPR operands of the tap FMAs), synthesises
-//                      H / tx / rx and the LS + MMSE estimates on chip and only WRITES to HBM, 16 B per lane
-//                      (1 KiB per wave store).  Its few vector loads (pilot slots, plan records) are issued one
-//                      symbol ahead of the stores so that no load waits behind HBM write latency (vmcnt is in-order).
+//   frame_kernel (K2)  one workgroup per frame, WAVE <-> OFDM symbol, lane <-> aligned subcarrier pairs.  A wave
+//                      produces the rows of its symbol one after the other, so each wave writes long sequential
+//                      runs (the write schedule MI355X's HBM likes: ~95 % of a flat fill, vs ~65 % when waves
+//                      interleave at 1 KiB -- tools/micro/store_wave_runs.hip).  Tap gains come in through SCALAR
+//                      loads (SGPR operands of the FMAs), tap twiddles from an LDS table built once per frame;
+//                      everything else lives in registers and the kernel only WRITES to HBM, 16 B per lane.
 #include "chest_device.h"
 #include "chest_internal.h"
 
@@ -146,68 +147,37 @@ taps_kernel(const FrameParams fp, const chest_frame_desc* __restrict__ descs, in
 // ================================================================================================
 // K2: the streaming frame kernel
 // ================================================================================================
-// Thread <-> TWO adjacent subcarriers (k0 even, k1 = k0 + 1).  A wave covers 128 subcarriers starting at
-// 126*wave, i.e. consecutive waves overlap by two: lane 63 recomputes what lane 0 of the next wave owns and only
-// serves as a shuffle source.  Every output row has nsc (odd) complex64 elements, so rows alternate between
-// 16-B aligned and 8-B shifted starts ("parity").  Aligned rows are stored as float4 (k0,k1); shifted rows as
-// float4 (k1, k0+2) with k0+2 fetched from lane+1 -- every store is a 16-B, 1-KiB-per-wave transaction
-// (6.9 TB/s store ceiling instead of 4.9 TB/s for 8-B stores, tools/micro/store_pattern.hip).
+// Lane <-> aligned subcarrier pair (k0 even, k1 = k0 + 1).  A wave sweeps its symbol in chunks of 126 subcarriers
+// (128 lanes' worth; lane 63 recomputes the pair lane 0 owns in the next chunk and only feeds the shuffle).
+// Every output row has nsc (odd) complex64 elements, so rows alternate between 16-B aligned and 8-B shifted
+// starts ("parity").  Aligned rows are stored as float4 (k0,k1); shifted rows as float4 (k1, k0+2) with k0+2
+// fetched from lane+1: every store is 16-B aligned, and consecutive stores of a wave are consecutive in memory.
 struct RowGeom {
-    int k0;           // first subcarrier of the lane (even)
-    int nsc;
+    unsigned k0;      // first subcarrier of the lane (even)
+    unsigned nsc;
     bool storer;      // lane < 63
-    bool first;       // global wave 0, lane 0 (owns the leading single element of shifted rows)
+    bool first;       // chunk 0, lane 0 (owns the leading single element of shifted rows)
 };
 
 __device__ __forceinline__ float2 from_next_lane(float2 v) {
     return make_float2(__shfl_down(v.x, 1, 64), __shfl_down(v.y, 1, 64));
 }
 
-// row: 32-bit element offset of the row start inside the frame's array; par: (absolute element offset) & 1
-__device__ __forceinline__ void store_pair(float2* __restrict__ base, unsigned row, int par, const RowGeom& g,
+// rowp: wave-uniform pointer to the row start (SGPR base + 32-bit lane offset addressing);
+// par: (absolute element offset of the row start) & 1
+__device__ __forceinline__ void store_pair(float2* __restrict__ rowp, int par, const RowGeom& g,
                                            float2 v0, float2 v1, float2 n0) {
     if (par == 0) {
         if (g.storer) {
-            if (g.k0 + 1 < g.nsc) *(float4*)(base + row + g.k0) = make_float4(v0.x, v0.y, v1.x, v1.y);
-            else if (g.k0 < g.nsc) base[row + g.k0] = v0;
+            if (g.k0 + 1 < g.nsc) *(float4*)(rowp + g.k0) = make_float4(v0.x, v0.y, v1.x, v1.y);
+            else if (g.k0 < g.nsc) rowp[g.k0] = v0;
         }
     } else {
         if (g.storer) {
-            if (g.k0 + 2 < g.nsc) *(float4*)(base + row + g.k0 + 1) = make_float4(v1.x, v1.y, n0.x, n0.y);
-            else if (g.k0 + 1 < g.nsc) base[row + g.k0 + 1] = v1;
+            if (g.k0 + 2 < g.nsc) *(float4*)(rowp + 1 + g.k0) = make_float4(v1.x, v1.y, n0.x, n0.y);
+            else if (g.k0 + 1 < g.nsc) (rowp + 1)[g.k0] = v1;
         }
-        if (g.first) base[row] = v0;
-    }
-}
-
-template <int NT>
-__device__ __forceinline__ void twiddles2(float2 (&W0)[NT], float2 (&W1)[NT], int k0, const TapProfile& prof,
-                                          int half, int N) {
-    const int ka = (k0 < half) ? (k0 - half) : (k0 - half + 1);
-    const int kb = (k0 + 1 < half) ? (k0 + 1 - half) : (k0 + 2 - half);
-    const float invN = 1.0f / (float)N;
-#pragma unroll
-    for (int d = 0; d < NT; ++d) {
-        int ma = (ka * prof.delay[d]) % N, mb = (kb * prof.delay[d]) % N;
-        if (ma < 0) ma += N;
-        if (mb < 0) mb += N;
-        const float2 ea = cis_unit((float)ma * invN), eb = cis_unit((float)mb * invN);
-        W0[d] = make_float2(ea.x, -ea.y);
-        W1[d] = make_float2(eb.x, -eb.y);
-    }
-}
-
-// two tap sums sharing the wave-uniform coefficients (scalar loads -> SGPR operands)
-template <int NT>
-__device__ __forceinline__ void tap_dot2(const float2* __restrict__ coef, const float2 (&W0)[NT],
-                                         const float2 (&W1)[NT], float2& a0, float2& a1) {
-    a0 = make_float2(0.f, 0.f);
-    a1 = make_float2(0.f, 0.f);
-#pragma unroll
-    for (int d = 0; d < NT; ++d) {
-        const float2 c = coef[d];
-        cfma(a0, c, W0[d]);
-        cfma(a1, c, W1[d]);
+        if (g.first) rowp[0] = v0;
     }
 }
 
@@ -220,26 +190,27 @@ struct FrameArgs {
     const float2* csum_g;
     const chest_injected* inj;
     const chest_frame_outputs* out;
-    float2* hp;
+    float2* tw;        // LDS [KT][tw_stride] twiddle table exp(-2 pi j kappa_k delay_d / N)
+    float2* hp;        // LDS [Pmax*R] LS estimates at the pilots
     float* red;
     float* alpha;
+    int tw_stride;     // float2 elements per tap row (even)
     RngKey key;
     int b;
     int par_tx, par_rx, par_h;     // parity of the frame's first element in each array
 };
 
-// TT / RR: compile-time antenna counts (0 = use the runtime values)
-template <int NT, int TT, int RR>
-__device__ __forceinline__ void frame_body(const FrameArgs& A) {
+template <int NT>
+__device__ __forceinline__ void frame_body(const FrameArgs& A, int nch) {
     const FrameParams& fp = *A.fp;
     const PatternDev& pat = *A.pat;
     const chest_injected& inj = *A.inj;
     const chest_frame_outputs& out = *A.out;
-    const int S = fp.S, nsc = fp.nsc, G = fp.G, P = pat.P, b = A.b;
-    const int T = TT ? TT : fp.T, R = RR ? RR : fp.R;
-    constexpr int TU = (TT == 0 || TT == 1) ? 1 : 2;         // tx rows computed back to back (TT is even or 1)
-    const int R2 = (R + 1) >> 1;
+    const int S = fp.S, G = fp.G, P = pat.P, b = A.b, T = fp.T, R = fp.R;
+    const unsigned nsc = (unsigned)fp.nsc;
     const int tid = threadIdx.x, lane = tid & 63, nwave = blockDim.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // provably wave-uniform -> SGPR indices, scalar loads
+    const unsigned npair = (nsc + 1) >> 1;
     const float noise_std = A.rec[ST_NOISE_STD];
     float2* __restrict__ hp = A.hp;
     float2* __restrict__ txb = out.tx ? (float2*)out.tx + (size_t)b * S * T * nsc : nullptr;
@@ -252,91 +223,102 @@ __device__ __forceinline__ void frame_body(const FrameArgs& A) {
     const float* __restrict__ nre = inj.n_re ? inj.n_re + (size_t)b * S * R * nsc : nullptr;
     const float* __restrict__ nim = inj.n_im ? inj.n_im + (size_t)b * S * R * nsc : nullptr;
     const uint16_t* __restrict__ slots = pat.slot;
-    const int nwg = (nsc + 125) / 126;                        // waves needed to cover the subcarriers
+    const float4* __restrict__ tw4 = (const float4*)A.tw;
+    const int tws4 = A.tw_stride >> 1;
 
-    // ---- phase W: H, tx, rx (+noise), LS at pilots ----------------------------------------------
-    for (int wg = tid >> 6; wg < nwg; wg += nwave) {
-        RowGeom g;
-        g.k0 = wg * 126 + 2 * lane; g.nsc = nsc; g.storer = lane < 63; g.first = (wg == 0 && lane == 0);
-        const int k0 = g.k0;
-        const bool v0ok = k0 < nsc, v1ok = k0 + 1 < nsc;
-        const int kc0 = v0ok ? k0 : nsc - 1, kc1 = v1ok ? k0 + 1 : nsc - 1;     // clamped (loads / rng only)
-        float2 W0[NT], W1[NT];
-        twiddles2<NT>(W0, W1, kc0 == k0 ? k0 : 0, *A.prof, fp.half, fp.N);
-        u32x4 sw0 = {0, 0, 0, 0}, sw1 = {0, 0, 0, 0};
-        int slot0 = slots[kc0], slot1 = slots[kc1];                              // prefetched one symbol ahead
-        for (int s = 0; s < S; ++s) {
-            const int sl0 = slot0, sl1 = slot1;
-            if (s + 1 < S) { slot0 = slots[(s + 1) * nsc + kc0]; slot1 = slots[(s + 1) * nsc + kc1]; }
+    // ---- twiddle table exp(-2 pi j kappa_k delay_d / N), all taps x all (padded) subcarriers -------------
+    {
+        const float invN = 1.0f / (float)fp.N;
+        const int half = fp.half, tws = A.tw_stride;
+        for (int i = tid; i < NT * tws; i += blockDim.x) {
+            const int d = i / tws, k = i - d * tws;
+            const int kappa = (k < half) ? (k - half) : (k - half + 1);
+            const float2 e = cis_turns((float)(kappa * A.prof->delay[d]) * invN);   // |kappa*delay| < 2^24: exact
+            A.tw[i] = make_float2(e.x, -e.y);
+        }
+    }
+    __syncthreads();
+
+    // ---- phase W: wave <-> symbol; per 126-subcarrier chunk: tx rows, then per rx antenna the H rows and the rx row.
+    //      The wave's stores walk a handful of short sequential streams inside its own symbol slice.
+    for (int s = wave; s < S; s += nwave) {
+        unsigned k0 = 2u * lane;
+        unsigned kc0 = k0 < nsc ? k0 : nsc - 1, kc1 = k0 + 1 < nsc ? k0 + 1 : nsc - 1;
+        const uint16_t* __restrict__ srow = slots + (unsigned)s * nsc;
+        uint32_t sl0 = srow[kc0], sl1 = srow[kc1];                               // prefetched one chunk ahead
+        for (int j = 0; j < nch; ++j) {
+            const RowGeom g{k0, nsc, lane < 63, j == 0 && lane == 0};
+            const unsigned s0 = sl0, s1 = sl1;
+            const unsigned kn = k0 + 126;
+            const unsigned kn0 = kn < nsc ? kn : nsc - 1, kn1 = kn + 1 < nsc ? kn + 1 : nsc - 1;
+            if (j + 1 < nch) { sl0 = srow[kn0]; sl1 = srow[kn1]; }
             float u0, u1;
             if (usym != nullptr) {
-                u0 = usym[sl0]; u1 = usym[sl1];
+                u0 = usym[s0]; u1 = usym[s1];
             } else {
-                if ((s & 3) == 0) {
-                    sw0 = draw(A.key, STREAM_SYM, (uint32_t)((s >> 2) * nsc + kc0));
-                    sw1 = draw(A.key, STREAM_SYM, (uint32_t)((s >> 2) * nsc + kc1));
-                }
-                u0 = u01(word(sw0, s & 3)); u1 = u01(word(sw1, s & 3));
+                const u32x4 w = draw(A.key, STREAM_SYM, (uint32_t)s * npair + (k0 >> 1));
+                u0 = u01(w.x); u1 = u01(w.y);
             }
-            const float2 x0 = cis_unit(__builtin_amdgcn_fractf(u0));            // exp(j 2pi u) (:395,:399)
+            const float2 x0 = cis_unit(__builtin_amdgcn_fractf(u0));             // exp(j 2pi u) (:395,:399)
             const float2 x1 = cis_unit(__builtin_amdgcn_fractf(u1));
-            const float2 xn = from_next_lane(x0);
             if (txb != nullptr) {
-#pragma unroll 1
-                for (int t = 0; t < T; ++t) { const unsigned row = (unsigned)((s * T + t) * nsc); store_pair(txb, row, (A.par_tx + row) & 1, g, x0, x1, xn); }
-            }
-            const bool p0 = v0ok && sl0 < P, p1 = v1ok && sl1 < P;
-            if (psb != nullptr && g.storer) {
-                if (p0) psb[sl0] = x0;
-                if (p1) psb[sl1] = x1;
-            }
-            u32x4 nz0 = {0, 0, 0, 0}, nz1 = {0, 0, 0, 0};
-#pragma unroll 1
-            for (int r = 0; r < R; ++r) {
-                {
-                    float2 hs0 = make_float2(0.f, 0.f), hs1 = make_float2(0.f, 0.f);
-                    if (Hb != nullptr) {
-#pragma unroll 1
-                        for (int tb = 0; tb < T; tb += TU) {
-#pragma unroll
-                            for (int tu = 0; tu < TU; ++tu) {
-                                const int t = tb + tu;
-                                float2 h0, h1;
-                                tap_dot2<NT>(A.c_g + ((s * R + r) * T + t) * KTS, W0, W1, h0, h1);
-                                const unsigned row = (unsigned)(((s * R + r) * T + t) * nsc);
-                                store_pair(Hb, row, (A.par_h + row) & 1, g, h0, h1, from_next_lane(h0));
-                                hs0.x += h0.x; hs0.y += h0.y; hs1.x += h1.x; hs1.y += h1.y;
-                            }
-                        }
-                    } else {
-                        tap_dot2<NT>(A.csum_g + (s * R + r) * KTS, W0, W1, hs0, hs1);
-                    }
-                    const float2 y0 = cmul(hs0, x0), y1 = cmul(hs1, x1);         // y = sum_t H x (:330-334)
-                    float2 n0v, n1v;
-                    if (nre != nullptr) {
-                        const int ni = (s * R + r) * nsc;
-                        n0v = make_float2(nre[ni + kc0], nim[ni + kc0]);
-                        n1v = make_float2(nre[ni + kc1], nim[ni + kc1]);
-                    } else {
-                        if ((r & 1) == 0) {
-                            nz0 = draw(A.key, STREAM_NOISE, (uint32_t)((s * R2 + (r >> 1)) * nsc + kc0));
-                            nz1 = draw(A.key, STREAM_NOISE, (uint32_t)((s * R2 + (r >> 1)) * nsc + kc1));
-                        }
-                        n0v = (r & 1) ? gauss_pair(nz0.z, nz0.w) : gauss_pair(nz0.x, nz0.y);
-                        n1v = (r & 1) ? gauss_pair(nz1.z, nz1.w) : gauss_pair(nz1.x, nz1.y);
-                    }
-                    const float2 r0 = make_float2(fmaf(noise_std, n0v.x, y0.x), fmaf(noise_std, n0v.y, y0.y));
-                    const float2 r1 = make_float2(fmaf(noise_std, n1v.x, y1.x), fmaf(noise_std, n1v.y, y1.y));
-                    if (rxb != nullptr) {
-                        const unsigned row = (unsigned)((s * R + r) * nsc);
-                        store_pair(rxb, row, (A.par_rx + row) & 1, g, r0, r1, from_next_lane(r0));
-                    }
-                    if (g.storer) {                                              // (src/baseline_estimators.py:110)
-                        if (p0) hp[sl0 * R + r] = pilot_divide(r0, x0);
-                        if (p1) hp[sl1 * R + r] = pilot_divide(r1, x1);
-                    }
+                const float2 xn = from_next_lane(x0);
+                for (int t = 0; t < T; ++t) {
+                    const unsigned row = (unsigned)(s * T + t) * nsc;
+                    store_pair(txb + row, (A.par_tx + row) & 1, g, x0, x1, xn);
                 }
             }
+            const bool p0 = lane < 63 && k0 < nsc && s0 < (unsigned)P, p1 = lane < 63 && k0 + 1 < nsc && s1 < (unsigned)P;
+            if (psb != nullptr) {
+                if (p0) psb[s0] = x0;
+                if (p1) psb[s1] = x1;
+            }
+            float4 w[NT];                                                        // twiddles of the pair, all taps
+#pragma unroll
+            for (int d = 0; d < NT; ++d) w[d] = tw4[d * tws4 + j * 63 + lane];
+            for (int r = 0; r < R; ++r) {
+                float2 hs0 = make_float2(0.f, 0.f), hs1 = make_float2(0.f, 0.f);
+                if (Hb != nullptr) {
+                    for (int t = 0; t < T; ++t) {
+                        const float2* __restrict__ coef = A.c_g + ((s * R + r) * T + t) * KTS;
+                        float2 h0 = make_float2(0.f, 0.f), h1 = make_float2(0.f, 0.f);
+#pragma unroll
+                        for (int d = 0; d < NT; ++d) {
+                            const float2 c = coef[d];
+                            cfma(h0, c, make_float2(w[d].x, w[d].y));
+                            cfma(h1, c, make_float2(w[d].z, w[d].w));
+                        }
+                        const unsigned row = (unsigned)((s * R + r) * T + t) * nsc;
+                        store_pair(Hb + row, (A.par_h + row) & 1, g, h0, h1, from_next_lane(h0));
+                        hs0.x += h0.x; hs0.y += h0.y; hs1.x += h1.x; hs1.y += h1.y;
+                    }
+                } else {
+                    const float2* __restrict__ coef = A.csum_g + (s * R + r) * KTS;
+#pragma unroll
+                    for (int d = 0; d < NT; ++d) {
+                        const float2 c = coef[d];
+                        cfma(hs0, c, make_float2(w[d].x, w[d].y));
+                        cfma(hs1, c, make_float2(w[d].z, w[d].w));
+                    }
+                }
+                const unsigned row = (unsigned)(s * R + r) * nsc;
+                const float2 y0 = cmul(hs0, x0), y1 = cmul(hs1, x1);             // y = sum_t H x (:330-334)
+                float2 n0v, n1v;
+                if (nre != nullptr) {
+                    n0v = make_float2((nre + row)[kc0], (nim + row)[kc0]);
+                    n1v = make_float2((nre + row)[kc1], (nim + row)[kc1]);
+                } else {
+                    const u32x4 z = draw(A.key, STREAM_NOISE, (uint32_t)(s * R + r) * npair + (k0 >> 1));
+                    n0v = gauss_pair(z.x, z.y);
+                    n1v = gauss_pair(z.z, z.w);
+                }
+                const float2 r0 = make_float2(fmaf(noise_std, n0v.x, y0.x), fmaf(noise_std, n0v.y, y0.y));
+                const float2 r1 = make_float2(fmaf(noise_std, n1v.x, y1.x), fmaf(noise_std, n1v.y, y1.y));
+                if (rxb != nullptr) store_pair(rxb + row, (A.par_rx + row) & 1, g, r0, r1, from_next_lane(r0));
+                if (p0) hp[s0 * R + r] = pilot_divide(r0, x0);                   // (src/baseline_estimators.py:110)
+                if (p1) hp[s1 * R + r] = pilot_divide(r1, x1);
+            }
+            k0 = kn; kc0 = kn0; kc1 = kn1;
         }
     }
     const bool want_metrics = out.metrics != nullptr;
@@ -357,55 +339,58 @@ __device__ __forceinline__ void frame_body(const FrameArgs& A) {
     __syncthreads();
 
     // ---- phase E: plan-driven interpolation (griddata linear/nearest as a 3-point gather), ----------
-    //      tx-broadcast stores (quirk Q9), optional error sums.
+    //      tx-broadcast stores (quirk Q9), optional error sums.  Again wave <-> symbol, chunk by chunk.
     const PlanRec* __restrict__ plan = (const PlanRec*)pat.plan;
     const float invT = 1.0f / (float)T;
     float m_ls = 0.f, m_mm = 0.f;
-    for (int wg = tid >> 6; wg < nwg; wg += nwave) {
-        RowGeom g;
-        g.k0 = wg * 126 + 2 * lane; g.nsc = nsc; g.storer = lane < 63; g.first = (wg == 0 && lane == 0);
-        const int k0 = g.k0;
-        const bool v0ok = k0 < nsc, v1ok = k0 + 1 < nsc;
-        const int kc0 = v0ok ? k0 : nsc - 1, kc1 = v1ok ? k0 + 1 : nsc - 1;
-        float2 W0[NT], W1[NT];
-        if (want_metrics) twiddles2<NT>(W0, W1, kc0 == k0 ? k0 : 0, *A.prof, fp.half, fp.N);
-        PlanRec q0 = plan[kc0], q1 = plan[kc1];                                   // prefetched one symbol ahead
-        for (int s = 0; s < S; ++s) {
+    for (int s = wave; s < S; s += nwave) {
+        unsigned k0 = 2u * lane;
+        unsigned kc0 = k0 < nsc ? k0 : nsc - 1, kc1 = k0 + 1 < nsc ? k0 + 1 : nsc - 1;
+        const PlanRec* __restrict__ prow = plan + (unsigned)s * nsc;
+        PlanRec q0 = prow[kc0], q1 = prow[kc1];                                  // prefetched one chunk ahead
+        for (int j = 0; j < nch; ++j) {
+            const RowGeom g{k0, nsc, lane < 63, j == 0 && lane == 0};
             const PlanRec c0 = q0, c1 = q1;
-            if (s + 1 < S) { q0 = plan[(s + 1) * nsc + kc0]; q1 = plan[(s + 1) * nsc + kc1]; }
-#pragma unroll 1
+            const unsigned kn = k0 + 126;
+            const unsigned kn0 = kn < nsc ? kn : nsc - 1, kn1 = kn + 1 < nsc ? kn + 1 : nsc - 1;
+            if (j + 1 < nch) { q0 = prow[kn0]; q1 = prow[kn1]; }
             for (int r = 0; r < R; ++r) {
-                {
-                    const float2 e0 = interp(c0, hp, R, r), e1 = interp(c1, hp, R, r);
-                    const float2 en = from_next_lane(e0);
-                    const float al = A.alpha[r];
-                    const float2 f0 = make_float2(al * e0.x, al * e0.y), f1 = make_float2(al * e1.x, al * e1.y);
-                    const float2 fn = make_float2(al * en.x, al * en.y);
-#pragma unroll 1
-                    for (int t = 0; t < T; ++t) {
-                        const unsigned row = (unsigned)(((s * R + r) * T + t) * nsc);
-                        const int par = (A.par_h + row) & 1;
-                        if (Lb != nullptr) store_pair(Lb, row, par, g, e0, e1, en);
-                        if (Mb != nullptr) store_pair(Mb, row, par, g, f0, f1, fn);
+                const float2 e0 = interp(c0, hp, R, r), e1 = interp(c1, hp, R, r);
+                const float2 en = from_next_lane(e0);
+                const float al = A.alpha[r];
+                const float2 f0 = make_float2(al * e0.x, al * e0.y), f1 = make_float2(al * e1.x, al * e1.y);
+                const float2 fn = make_float2(al * en.x, al * en.y);
+                for (int t = 0; t < T; ++t) {
+                    const unsigned row = (unsigned)((s * R + r) * T + t) * nsc;
+                    const int par = (A.par_h + row) & 1;
+                    if (Lb != nullptr) store_pair(Lb + row, par, g, e0, e1, en);
+                    if (Mb != nullptr) store_pair(Mb + row, par, g, f0, f1, fn);
+                }
+                if (want_metrics) {
+                    // sum_t |H_t - v|^2 = sum_t |H_t - Hbar|^2 + T |Hbar - v|^2 ; the first term is
+                    // estimate-independent and comes analytically from K1 (ST_SUM_VAR).
+                    const float2* __restrict__ coef = A.csum_g + (s * R + r) * KTS;
+                    float2 hb0 = make_float2(0.f, 0.f), hb1 = make_float2(0.f, 0.f);
+#pragma unroll
+                    for (int d = 0; d < NT; ++d) {
+                        const float2 c = coef[d];
+                        const float4 w = tw4[d * tws4 + j * 63 + lane];
+                        cfma(hb0, c, make_float2(w.x, w.y));
+                        cfma(hb1, c, make_float2(w.z, w.w));
                     }
-                    if (want_metrics) {
-                        // sum_t |H_t - v|^2 = sum_t |H_t - Hbar|^2 + T |Hbar - v|^2 ; the first term is
-                        // estimate-independent and comes analytically from K1 (ST_SUM_VAR).
-                        float2 hb0, hb1;
-                        tap_dot2<NT>(A.csum_g + (s * R + r) * KTS, W0, W1, hb0, hb1);
-                        if (g.storer && v0ok) {
-                            const float2 m = make_float2(hb0.x * invT, hb0.y * invT);
-                            m_ls += cabs2(make_float2(m.x - e0.x, m.y - e0.y));
-                            m_mm += cabs2(make_float2(m.x - f0.x, m.y - f0.y));
-                        }
-                        if (g.storer && v1ok) {
-                            const float2 m = make_float2(hb1.x * invT, hb1.y * invT);
-                            m_ls += cabs2(make_float2(m.x - e1.x, m.y - e1.y));
-                            m_mm += cabs2(make_float2(m.x - f1.x, m.y - f1.y));
-                        }
+                    if (lane < 63 && k0 < nsc) {
+                        const float2 m = make_float2(hb0.x * invT, hb0.y * invT);
+                        m_ls += cabs2(make_float2(m.x - e0.x, m.y - e0.y));
+                        m_mm += cabs2(make_float2(m.x - f0.x, m.y - f0.y));
+                    }
+                    if (lane < 63 && k0 + 1 < nsc) {
+                        const float2 m = make_float2(hb1.x * invT, hb1.y * invT);
+                        m_ls += cabs2(make_float2(m.x - e1.x, m.y - e1.y));
+                        m_mm += cabs2(make_float2(m.x - f1.x, m.y - f1.y));
                     }
                 }
             }
+            k0 = kn; kc0 = kn0; kc1 = kn1;
         }
     }
     if (want_metrics) {
@@ -417,18 +402,25 @@ __device__ __forceinline__ void frame_body(const FrameArgs& A) {
             m[CHEST_M_SUM_ERR_LS] = A.rec[ST_SUM_VAR] + (float)T * m_ls;
             m[CHEST_M_SUM_ERR_MMSE] = A.rec[ST_SUM_VAR] + (float)T * m_mm;
             m[CHEST_M_SIGNAL_POWER] = A.rec[ST_SIGNAL_POWER]; m[CHEST_M_NOISE_STD] = noise_std;
-            m[CHEST_M_ALPHA0] = A.alpha[0]; m[CHEST_M_COUNT] = (float)(S * R * T) * (float)nsc;
+            m[CHEST_M_ALPHA0] = A.alpha[0]; m[CHEST_M_COUNT] = (float)(S * R * T) * (float)fp.nsc;
             m[CHEST_M_RESERVED] = 0.f;
         }
     }
 }
 
-template <int TT, int RR>
-__global__ void __launch_bounds__(1024)
+__host__ __device__ inline int frame_tw_stride(int nch) { return nch * 126 + 2; }     // float2 per tap row (even)
+
+#ifndef CHEST_K2_BOUNDS
+#define CHEST_K2_BOUNDS 1024
+#endif
+#ifndef CHEST_K2_MINWAVES
+#define CHEST_K2_MINWAVES 1
+#endif
+__global__ void __launch_bounds__(CHEST_K2_BOUNDS, CHEST_K2_MINWAVES)
 frame_kernel(const FrameParams fp, const chest_frame_desc* __restrict__ descs,
              const PatternDev* __restrict__ patterns, int Pmax, uint64_t seed, uint64_t frame_offset,
              const chest_injected inj, const chest_frame_outputs out, const float* __restrict__ state,
-             int* __restrict__ status) {
+             int nch, int* __restrict__ status) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const int b = blockIdx.x, tid = threadIdx.x;
     const int S = fp.S, T = fp.T, R = fp.R, nsc = fp.nsc, G = fp.G;
@@ -465,7 +457,9 @@ frame_kernel(const FrameParams fp, const chest_frame_desc* __restrict__ descs,
     A.c_g = (const float2*)(rec + ST_SCAL);
     A.csum_g = A.c_g + (size_t)S * R * T * KTS;
     A.inj = &inj; A.out = &out;
-    A.hp = (float2*)lds_raw;                                     // [Pmax*R] LS estimates at the pilots
+    A.tw_stride = frame_tw_stride(nch);
+    A.tw = (float2*)lds_raw;                                     // [KT][tw_stride]
+    A.hp = A.tw + (size_t)KT * A.tw_stride;                      // [Pmax*R]
     A.red = (float*)(A.hp + (size_t)Pmax * R);                   // [32]
     A.alpha = A.red + 32;                                        // [8]
     const uint64_t frame = frame_offset + (uint64_t)b;
@@ -475,9 +469,9 @@ frame_kernel(const FrameParams fp, const chest_frame_desc* __restrict__ descs,
     A.par_rx = (int)(((size_t)b * S * R * nsc) & 1);
     A.par_h = (int)(((size_t)b * S * R * T * nsc) & 1);
     switch (A.prof->ntaps) {                                     // workgroup-uniform dispatch on the profile
-        case 5: frame_body<5, TT, RR>(A); break;                 // EPA at 15.36 MHz
-        case 8: frame_body<8, TT, RR>(A); break;                 // EVA
-        default: frame_body<KT, TT, RR>(A); break;               // ETU / anything else (taps padded with zeros)
+        case 5: frame_body<5>(A, nch); break;                    // EPA at 15.36 MHz
+        case 8: frame_body<8>(A, nch); break;                    // EVA
+        default: frame_body<KT>(A, nch); break;                  // ETU / anything else (taps padded with zeros)
     }
 }
 
@@ -485,17 +479,22 @@ size_t frames_workspace_bytes(const chest_ctx* ctx, int64_t B) {
     return (size_t)B * frame_state_floats(ctx->fp.S, ctx->fp.R, ctx->fp.T) * sizeof(float);
 }
 
-template <int TT, int RR>
-static int launch_k2(chest_ctx* ctx, hipStream_t st, int32_t B, size_t lds2, const chest_frame_desc* descs, int Pmax,
+static size_t k2_lds_bytes(int nch, int Pmax, int R) {
+    return ((size_t)KT * frame_tw_stride(nch) + (size_t)Pmax * R) * sizeof(float2) + 40 * sizeof(float);
+}
+
+static int launch_k2(chest_ctx* ctx, hipStream_t st, int32_t B, int nch, const chest_frame_desc* descs, int Pmax,
                      uint64_t seed, uint64_t frame_offset, const chest_injected& inj, const chest_frame_outputs& out,
                      const float* workspace) {
+    const size_t lds2 = k2_lds_bytes(nch, Pmax, ctx->fp.R);
+    if (lds2 > 160 * 1024) { set_error("frame kernel needs %zu B of LDS (> 160 KiB): too many antennas or pilots", lds2); return CHEST_EINVAL; }
     static thread_local size_t attr = 0;
     if (lds2 > 64 * 1024 && lds2 > attr) {
-        CHEST_HIP(hipFuncSetAttribute((const void*)frame_kernel<TT, RR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+        CHEST_HIP(hipFuncSetAttribute((const void*)frame_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
         attr = lds2;
     }
-    hipLaunchKernelGGL((frame_kernel<TT, RR>), dim3(B), dim3(ctx->block_threads), lds2, st, ctx->fp, descs, ctx->d_patterns,
-                       Pmax, seed, frame_offset, inj, out, workspace, ctx->d_status);
+    hipLaunchKernelGGL(frame_kernel, dim3(B), dim3(ctx->block_threads), lds2, st, ctx->fp, descs, ctx->d_patterns,
+                       Pmax, seed, frame_offset, inj, out, workspace, nch, ctx->d_status);
     return CHEST_OK;
 }
 
@@ -515,11 +514,7 @@ int launch_frames(chest_ctx* ctx, hipStream_t st, int32_t B, const chest_frame_d
     int Pmax = 1;
     for (const auto& p : ctx->patterns) Pmax = p.dev.P > Pmax ? p.dev.P : Pmax;
     const size_t lds1 = ((size_t)KT * fp.T * fp.R * CHEST_NUM_OSC + (size_t)fp.S * fp.R * KTS) * sizeof(float2) + 32 * sizeof(float);
-    const size_t lds2 = (size_t)Pmax * fp.R * sizeof(float2) + 40 * sizeof(float);
-    if (lds1 > 160 * 1024 || lds2 > 160 * 1024) {
-        set_error("frame pipeline needs %zu / %zu B of LDS (> 160 KiB): too many antennas or pilots", lds1, lds2);
-        return CHEST_EINVAL;
-    }
+    if (lds1 > 160 * 1024) { set_error("taps kernel needs %zu B of LDS (> 160 KiB): too many antennas", lds1); return CHEST_EINVAL; }
     static thread_local size_t attr1 = 0;
     if (lds1 > 64 * 1024 && lds1 > attr1) {
         CHEST_HIP(hipFuncSetAttribute((const void*)taps_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
@@ -531,13 +526,10 @@ int launch_frames(chest_ctx* ctx, hipStream_t st, int32_t B, const chest_frame_d
         set_error("injected u_angle/u_phase and n_re/n_im must be given in pairs");
         return CHEST_EINVAL;
     }
+    const int nch = (fp.nsc + 125) / 126;
     hipLaunchKernelGGL(taps_kernel, dim3(B), dim3(256), lds1, st, fp, descs, (int)ctx->patterns.size(), ctx->d_gram, seed,
                        frame_offset, inj_v.u_angle, inj_v.u_phase, inj_v.inj_paths, (float*)workspace, ctx->d_status);
-    int rc;
-    if (fp.T == 1 && fp.R == 1) rc = launch_k2<1, 1>(ctx, st, B, lds2, descs, Pmax, seed, frame_offset, inj_v, *out, (const float*)workspace);
-    else if (fp.T == 2 && fp.R == 2) rc = launch_k2<2, 2>(ctx, st, B, lds2, descs, Pmax, seed, frame_offset, inj_v, *out, (const float*)workspace);
-    else if (fp.T == 4 && fp.R == 4) rc = launch_k2<4, 4>(ctx, st, B, lds2, descs, Pmax, seed, frame_offset, inj_v, *out, (const float*)workspace);
-    else rc = launch_k2<0, 0>(ctx, st, B, lds2, descs, Pmax, seed, frame_offset, inj_v, *out, (const float*)workspace);
+    const int rc = launch_k2(ctx, st, B, nch, descs, Pmax, seed, frame_offset, inj_v, *out, (const float*)workspace);
     if (rc != CHEST_OK) return rc;
     CHEST_HIP(hipGetLastError());
     return CHEST_OK;

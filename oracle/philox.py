@@ -61,10 +61,10 @@ def native_frame_draws(seed, frame, pilot_indices, num_symbols, num_sc, num_tx, 
     """The engine's draws for global frame index ``frame`` in the oracle's input format."""
     S, nsc, T, R, L = num_symbols, num_sc, num_tx, num_rx, num_paths
     G = S * nsc
-    # symbol phase of RE (s, k): word (s & 3) of draw(index = (s >> 2)*nsc + k)
-    S4 = (S + 3) // 4
-    sw = draw(seed, frame, STREAM_SYM, np.arange(S4 * nsc))
-    u_re = np.stack([u01(w).reshape(S4, nsc) for w in sw], axis=1).reshape(S4 * 4, nsc)[:S]
+    # symbol phase of RE (s, k): word (k & 1) of draw(index = s*npair + (k >> 1)), npair = ceil(nsc/2)
+    npair = (nsc + 1) // 2
+    sw = draw(seed, frame, STREAM_SYM, np.arange(S * npair))
+    u_re = np.stack([u01(sw[0]), u01(sw[1])], axis=-1).reshape(S, npair * 2)[:, :nsc]
     mask = np.zeros(G, dtype=bool)
     mask[np.asarray(pilot_indices)] = True
     u_flat = u_re.reshape(-1)
@@ -72,15 +72,11 @@ def native_frame_draws(seed, frame, pilot_indices, num_symbols, num_sc, num_tx, 
     ox, oy, _, _ = draw(seed, frame, STREAM_OSC, np.arange(n_osc))
     u_angle = u01(ox).reshape(L, T, R, 20)
     u_phase = u01(oy).reshape(L, T, R, 20)
-    R2 = (R + 1) // 2
-    w = draw(seed, frame, STREAM_NOISE, np.arange(S * R2 * nsc))
-    n_re = np.empty((S, R, nsc))
-    n_im = np.empty((S, R, nsc))
-    for r in range(R):
-        a, b = (w[0], w[1]) if r % 2 == 0 else (w[2], w[3])
-        re, im = gauss_pair(a, b)
-        re = re.reshape(S, R2, nsc)[:, r // 2, :]
-        im = im.reshape(S, R2, nsc)[:, r // 2, :]
-        n_re[:, r, :], n_im[:, r, :] = re, im
+    # noise of RE (s, r, k): words (0,1) [k even] or (2,3) [k odd] of draw(index = (s*R + r)*npair + (k >> 1))
+    w = draw(seed, frame, STREAM_NOISE, np.arange(S * R * npair))
+    re0, im0 = gauss_pair(w[0], w[1])
+    re1, im1 = gauss_pair(w[2], w[3])
+    n_re = np.stack([re0, re1], axis=-1).reshape(S, R, npair * 2)[:, :, :nsc]
+    n_im = np.stack([im0, im1], axis=-1).reshape(S, R, npair * 2)[:, :, :nsc]
     return dict(pilot_indices=np.asarray(pilot_indices), u_pilot=u_flat[mask], u_data=u_flat[~mask], u_angle=u_angle,
                 u_phase=u_phase, n_re=n_re, n_im=n_im)

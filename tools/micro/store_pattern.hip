@@ -43,6 +43,43 @@ __global__ void __launch_bounds__(1024) storeB(float4* tx, float4* rx, float4* H
     for (int i = threadIdx.x; i < nH; i += blockDim.x) Hmm[(size_t)b * nH + i] = v;
 }
 
+// Variant C: what frame_kernel v3 does: thread <-> two adjacent subcarriers, wave covers 126 (+2 overlap),
+// 16-B stores, rows alternate between aligned and 8-B shifted (shifted rows take k0+2 from lane+1).
+__device__ __forceinline__ void store_pair(float2* base, unsigned row, int par, int k0, bool storer, bool first, float2 v0, float2 v1, float2 n0) {
+    if (par == 0) {
+        if (storer) {
+            if (k0 + 1 < NSC) *(float4*)(base + row + k0) = make_float4(v0.x, v0.y, v1.x, v1.y);
+            else if (k0 < NSC) base[row + k0] = v0;
+        }
+    } else {
+        if (storer) {
+            if (k0 + 2 < NSC) *(float4*)(base + row + k0 + 1) = make_float4(v1.x, v1.y, n0.x, n0.y);
+            else if (k0 + 1 < NSC) base[row + k0 + 1] = v1;
+        }
+        if (first) base[row] = v0;
+    }
+}
+__global__ void __launch_bounds__(1024) storeC(float2* tx, float2* rx, float2* H, float2* Hls, float2* Hmm) {
+    const int b = blockIdx.x, lane = threadIdx.x & 63;
+    float2* txb = tx + (size_t)b * S * T * NSC; float2* rxb = rx + (size_t)b * S * R * NSC;
+    float2* Hb = H + (size_t)b * S * R * T * NSC; float2* Lb = Hls + (size_t)b * S * R * T * NSC; float2* Mb = Hmm + (size_t)b * S * R * T * NSC;
+    for (int wg = threadIdx.x >> 6; wg < (NSC + 125) / 126; wg += blockDim.x >> 6) {
+        const int k0 = wg * 126 + 2 * lane; const bool storer = lane < 63, first = (wg == 0 && lane == 0);
+        const float2 v0 = make_float2((float)k0, (float)b), v1 = make_float2((float)k0 + 1, (float)b);
+        const float2 n0 = make_float2(__shfl_down(v0.x, 1, 64), __shfl_down(v0.y, 1, 64));
+        for (int s = 0; s < S; ++s) {
+            for (int t = 0; t < T; ++t) { unsigned row = (s * T + t) * NSC; store_pair(txb, row, row & 1, k0, storer, first, v0, v1, n0); }
+            for (int r = 0; r < R; ++r) {
+                for (int t = 0; t < T; ++t) { unsigned row = ((s * R + r) * T + t) * NSC; store_pair(Hb, row, row & 1, k0, storer, first, v0, v1, n0); }
+                unsigned row = (s * R + r) * NSC; store_pair(rxb, row, row & 1, k0, storer, first, v0, v1, n0);
+            }
+        }
+        for (int s = 0; s < S; ++s)
+            for (int r = 0; r < R; ++r)
+                for (int t = 0; t < T; ++t) { unsigned row = ((s * R + r) * T + t) * NSC; store_pair(Lb, row, row & 1, k0, storer, first, v0, v1, n0); store_pair(Mb, row, row & 1, k0, storer, first, v0, v1, n0); }
+    }
+}
+
 int main(int argc, char** argv) {
     const int B = 10000;
     const size_t nH = (size_t)B * S * R * T * NSC, nT = (size_t)B * S * T * NSC, nR = (size_t)B * S * R * NSC;
@@ -69,6 +106,14 @@ int main(int argc, char** argv) {
             printf("block %4d  %s  %7.3f ms  %7.1f GB/s\n", bt, variant == 0 ? "A: 8-B row-wise (thread<->k)" : "B: 16-B flat              ", ms, bytes / ms * 1e-6);
         }
     }
-    // grid-stride flat copy-less fill over everything, 2048 blocks (classic ceiling)
+    for (int bt : {64, 128, 320}) {
+        for (int it = 0; it < 3; ++it) storeC<<<B, bt>>>(tx, rx, H, Hls, Hmm);
+        CK(hipDeviceSynchronize());
+        CK(hipEventRecord(a));
+        for (int it = 0; it < 10; ++it) storeC<<<B, bt>>>(tx, rx, H, Hls, Hmm);
+        CK(hipEventRecord(c)); CK(hipEventSynchronize(c));
+        float ms; CK(hipEventElapsedTime(&ms, a, c)); ms /= 10;
+        printf("block %4d  C: 16-B row-wise pairs (v3)    %7.3f ms  %7.1f GB/s\n", bt, ms, bytes / ms * 1e-6);
+    }
     return 0;
 }
