@@ -1,0 +1,192 @@
+"""Drop-in replacement for the reference's ``src/baseline_estimators.py`` backed by the MI355X engine.
+
+``LSEstimator``, ``MMSEEstimator``, ``equalize_channel`` and ``evaluate_estimator`` keep the reference's
+names, signatures, shapes, error behaviour and quirks (``+1e-12`` in the pilot division, real and
+imaginary parts interpolated with the same barycentric weights, 0 outside the pilots' convex hull,
+MMSE always interpolating linearly, ``MMSEEstimator`` mutating ``noise_variance``).  The arithmetic
+runs in HIP kernels; the geometry-only part of ``scipy.interpolate.griddata`` (Qhull triangulation /
+nearest-neighbour lookup) is done once per pilot pattern on the host (``interp_plan``) and cached.
+
+NumPy in -> NumPy complex128 out (values carry complex64 precision); torch CUDA tensors in ->
+complex64 tensors out, staying in HBM.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import engine as _engine
+
+
+def _is_tensor(x):
+    return isinstance(x, torch.Tensor)
+
+
+def _engine_for(shape):
+    """Engine whose grid matches a (S, R, T, nsc) estimate shape.  Estimation does not depend on
+    fft_size / cp / spacing, so those take the defaults."""
+    S, R, T, nsc = (int(v) for v in shape)
+    if nsc % 2 == 0:
+        raise NotImplementedError("the engine handles DC-removed grids (odd subcarrier counts) only")
+    fft = 1024
+    while fft < nsc + 1:
+        fft *= 2
+    return _engine.get_engine(_engine.Geometry(fft_size=fft, num_symbols=S, useful_subcarriers=nsc + 1, num_tx=T, num_rx=R))
+
+
+def _back(t, like_numpy):
+    return t.cpu().numpy().astype(np.complex128) if like_numpy else t
+
+
+def _pilot_flat(pilot_positions, nsc):
+    ps = np.asarray(pilot_positions[0], dtype=np.int64)
+    pk = np.asarray(pilot_positions[1], dtype=np.int64)
+    return ps * nsc + pk
+
+
+def _prep(rx_symbols, pilot_mask, pilot_positions, method):
+    if rx_symbols.ndim != 4:
+        raise ValueError("rx_symbols must have shape (num_symbols, num_rx, num_tx, num_subcarriers)")
+    S, R, T, nsc = rx_symbols.shape
+    eng = _engine_for((S, R, T, nsc))
+    flat = _pilot_flat(pilot_positions, nsc)
+    if np.any(np.diff(flat) <= 0):
+        raise NotImplementedError("pilot_positions must be in row-major (sorted) order, as PilotPattern produces them")
+    mask = np.asarray(pilot_mask.cpu() if _is_tensor(pilot_mask) else pilot_mask, dtype=bool)
+    if mask.shape != (S, nsc) or int(mask.sum()) != len(flat) or not mask.reshape(-1)[flat].all():
+        raise ValueError("pilot_mask and pilot_positions describe different pilot sets")
+    slot = eng.pattern_slot(flat, method)
+    return eng, slot
+
+
+class LSEstimator:
+    """Least Squares channel estimator (reference src/baseline_estimators.py:10-117)."""
+
+    def __init__(self, interpolation_method: str = 'linear'):
+        self.interpolation_method = interpolation_method
+
+    def estimate_at_pilots(self, rx_symbols, tx_pilots, pilot_mask):
+        """h = y_p / (x_p + 1e-12) at the mask's True positions (:23-42)."""
+        like_np = not _is_tensor(rx_symbols)
+        rx = np.asarray(rx_symbols) if like_np else rx_symbols
+        m = np.asarray(pilot_mask, dtype=bool) if like_np else pilot_mask.to(torch.bool)
+        rx_p = rx[m]
+        eng = _engine.get_engine(_engine.Geometry())
+        return _back(eng.at_pilots(rx_p, tx_pilots, mmse=False), like_np)
+
+    def interpolate_channel(self, h_pilots, pilot_positions: Tuple, grid_shape: Tuple[int, int]):
+        """Scattered -> full-grid interpolation of pilot estimates (:44-81)."""
+        like_np = not _is_tensor(h_pilots)
+        S, nsc = grid_shape
+        eng = _engine_for((S, 1, 1, nsc))
+        slot = eng.pattern_slot(_pilot_flat(pilot_positions, nsc), self.interpolation_method)
+        # plant the pilot values on a grid with unit pilots: y/(1+1e-12) == y to float32 rounding
+        flat = _pilot_flat(pilot_positions, nsc)
+        hp = eng._c64(h_pilots).reshape(-1)
+        grid = torch.zeros(S * nsc, dtype=torch.complex64, device=eng.device)
+        grid[torch.from_numpy(flat).to(eng.device)] = hp
+        ones = torch.ones(len(flat), dtype=torch.complex64, device=eng.device)
+        out = eng.estimate(grid.reshape(1, S, 1, 1, nsc), ones, slot, mmse=False)
+        return _back(out[0, :, 0, 0, :], like_np)
+
+    def estimate(self, rx_symbols, tx_pilots, pilot_mask, pilot_positions: Tuple):
+        """Complete LS estimation with interpolation for every (rx, tx) grid (:83-117)."""
+        like_np = not _is_tensor(rx_symbols)
+        eng, slot = _prep(rx_symbols, pilot_mask, pilot_positions, self.interpolation_method)
+        out = eng.estimate(rx_symbols, tx_pilots, slot, mmse=False)
+        return _back(out[0], like_np)
+
+
+class MMSEEstimator:
+    """Minimum Mean Square Error channel estimator (reference src/baseline_estimators.py:120-270)."""
+
+    def __init__(self, channel_covariance: Optional[np.ndarray] = None, noise_variance: float = 0.01,
+                 estimate_statistics: bool = True):
+        self.channel_covariance = channel_covariance
+        self.noise_variance = noise_variance
+        self.estimate_statistics = estimate_statistics
+        self._W_cache = None          # (snr_db, id(cov)) -> W on device
+
+    def estimate_covariance(self, h_ls: np.ndarray) -> np.ndarray:
+        """np.cov over the flattened leading dimensions (:137-153); host-side helper nobody calls on the hot path."""
+        h = np.asarray(h_ls.cpu() if _is_tensor(h_ls) else h_ls)
+        return np.cov(h.reshape(-1, h.shape[-1]), rowvar=False)
+
+    def _uses_diagonal(self):
+        return self.estimate_statistics or self.channel_covariance is None
+
+    def _full_W(self, eng, snr_db):
+        key = (float(snr_db), id(self.channel_covariance), eng)
+        if self._W_cache is None or self._W_cache[0] != key:
+            self._W_cache = (key, eng.mmse_full_prepare(self.channel_covariance, snr_db))
+        return self._W_cache[1]
+
+    def estimate_at_pilots(self, rx_symbols, tx_pilots, pilot_mask, snr_db: float = 10):
+        """MMSE filtering of the LS pilot estimates; sets ``noise_variance = 10^(-snr/10)`` (:155-196)."""
+        like_np = not _is_tensor(rx_symbols)
+        rx = np.asarray(rx_symbols) if like_np else rx_symbols
+        m = np.asarray(pilot_mask, dtype=bool) if like_np else pilot_mask.to(torch.bool)
+        rx_p = rx[m]
+        self.noise_variance = 1.0 / (10 ** (snr_db / 10))
+        eng = _engine.get_engine(_engine.Geometry())
+        if self._uses_diagonal():
+            return _back(eng.at_pilots(rx_p, tx_pilots, mmse=True, snr_db=snr_db), like_np)
+        h_ls = eng.at_pilots(rx_p, tx_pilots, mmse=False)
+        W = self._full_W(eng, snr_db)
+        if W.shape[0] != h_ls.numel():
+            raise ValueError("channel_covariance size does not match the number of pilots")
+        # P x P times one right-hand side: route through the MFMA apply path with a 1x1x1 "grid" of pilots only
+        U = 2 * ((h_ls.numel() + 1) // 2) + 2
+        fft = 1024
+        while fft < U:
+            fft *= 2
+        geo = _engine.Geometry(fft_size=fft, num_symbols=1, useful_subcarriers=U, num_tx=1, num_rx=1)
+        e2 = _engine.get_engine(geo)
+        P = h_ls.numel()
+        slot = e2.pattern_slot(np.arange(P), "nearest")
+        grid = torch.zeros(1, 1, 1, 1, geo.num_sc, dtype=torch.complex64, device=e2.device)
+        grid[0, 0, 0, 0, :P] = h_ls
+        out = e2.mmse_full_apply(grid, torch.ones(P, dtype=torch.complex64, device=e2.device), slot, W)
+        return _back(out[0, 0, 0, 0, :P], like_np)
+
+    def interpolate_channel(self, h_pilots, pilot_positions: Tuple, grid_shape: Tuple[int, int],
+                            interpolation_method: str = 'linear'):
+        """Same interpolation as LSEstimator (:198-230)."""
+        return LSEstimator(interpolation_method).interpolate_channel(h_pilots, pilot_positions, grid_shape)
+
+    def estimate(self, rx_symbols, tx_pilots, pilot_mask, pilot_positions: Tuple, snr_db: float = 10):
+        """Complete MMSE estimation; interpolation is always 'linear' (:232-270)."""
+        like_np = not _is_tensor(rx_symbols)
+        eng, slot = _prep(rx_symbols, pilot_mask, pilot_positions, "linear")
+        self.noise_variance = 1.0 / (10 ** (snr_db / 10))
+        if self._uses_diagonal():
+            out = eng.estimate(rx_symbols, tx_pilots, slot, mmse=True, snr_db=snr_db)
+        else:
+            W = self._full_W(eng, snr_db)
+            out = eng.mmse_full_apply(rx_symbols, tx_pilots, slot, W)
+        return _back(out[0], like_np)
+
+
+def equalize_channel(rx_symbols, H_est, method: str = 'zf'):
+    """ZF / MMSE equalisation per resource element (reference src/baseline_estimators.py:273-312)."""
+    if method not in ('zf', 'mmse'):
+        raise ValueError(f"Unknown equalization method: {method}")
+    like_np = not _is_tensor(rx_symbols)
+    S, R, T, nsc = H_est.shape
+    eng = _engine_for((S, R, T, nsc))
+    return _back(eng.equalize(rx_symbols, H_est, method)[0], like_np)
+
+
+def evaluate_estimator(H_true, H_est) -> dict:
+    """mse / nmse / nmse_db with the reference's +1e-12 guards (src/baseline_estimators.py:315-337).
+    The two sums are reduced on the GPU in float64."""
+    n = int(np.prod(H_true.shape))
+    eng = _engine.get_engine(_engine.Geometry())
+    sums = eng.error_sums(H_true, H_est).cpu().numpy()
+    mse = sums[0] / n
+    channel_power = sums[1] / n
+    nmse = mse / (channel_power + 1e-12)
+    nmse_db = 10 * np.log10(nmse + 1e-12)
+    return {'mse': mse, 'nmse': nmse, 'nmse_db': nmse_db}

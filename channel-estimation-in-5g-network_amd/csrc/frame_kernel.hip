@@ -277,29 +277,23 @@ __device__ __forceinline__ void frame_body(const FrameArgs& A, int nch) {
 #pragma unroll
             for (int d = 0; d < NT; ++d) w[d] = tw4[d * tws4 + j * 63 + lane];
             for (int r = 0; r < R; ++r) {
+                // sum_t H_t is always accumulated from the per-tx rows, whether or not H is stored, so that rx / H_ls /
+                // H_mmse are bit-identical for every choice of requested outputs.
                 float2 hs0 = make_float2(0.f, 0.f), hs1 = make_float2(0.f, 0.f);
-                if (Hb != nullptr) {
-                    for (int t = 0; t < T; ++t) {
-                        const float2* __restrict__ coef = A.c_g + ((s * R + r) * T + t) * KTS;
-                        float2 h0 = make_float2(0.f, 0.f), h1 = make_float2(0.f, 0.f);
-#pragma unroll
-                        for (int d = 0; d < NT; ++d) {
-                            const float2 c = coef[d];
-                            cfma(h0, c, make_float2(w[d].x, w[d].y));
-                            cfma(h1, c, make_float2(w[d].z, w[d].w));
-                        }
-                        const unsigned row = (unsigned)((s * R + r) * T + t) * nsc;
-                        store_pair(Hb + row, (A.par_h + row) & 1, g, h0, h1, from_next_lane(h0));
-                        hs0.x += h0.x; hs0.y += h0.y; hs1.x += h1.x; hs1.y += h1.y;
-                    }
-                } else {
-                    const float2* __restrict__ coef = A.csum_g + (s * R + r) * KTS;
+                for (int t = 0; t < T; ++t) {
+                    const float2* __restrict__ coef = A.c_g + ((s * R + r) * T + t) * KTS;
+                    float2 h0 = make_float2(0.f, 0.f), h1 = make_float2(0.f, 0.f);
 #pragma unroll
                     for (int d = 0; d < NT; ++d) {
                         const float2 c = coef[d];
-                        cfma(hs0, c, make_float2(w[d].x, w[d].y));
-                        cfma(hs1, c, make_float2(w[d].z, w[d].w));
+                        cfma(h0, c, make_float2(w[d].x, w[d].y));
+                        cfma(h1, c, make_float2(w[d].z, w[d].w));
                     }
+                    if (Hb != nullptr) {
+                        const unsigned row = (unsigned)((s * R + r) * T + t) * nsc;
+                        store_pair(Hb + row, (A.par_h + row) & 1, g, h0, h1, from_next_lane(h0));
+                    }
+                    hs0.x += h0.x; hs0.y += h0.y; hs1.x += h1.x; hs1.y += h1.y;
                 }
                 const unsigned row = (unsigned)(s * R + r) * nsc;
                 const float2 y0 = cmul(hs0, x0), y1 = cmul(hs1, x1);             // y = sum_t H x (:330-334)

@@ -1,0 +1,221 @@
+"""Drop-in replacement for the reference's ``src/dataset_generator.py`` backed by the MI355X engine.
+
+``ChannelEstimationDataset.generate_sample / generate_dataset / save_dataset``, ``prepare_ml_inputs``
+and ``main`` keep the reference's names, signatures, sample keys and failure behaviour (failed
+samples are printed and skipped).  These calls consume the global ``np.random`` stream exactly like
+the reference (four ``np.random.choice`` per frame, then the frame's draws), one fused GPU launch per
+frame.
+
+The high-throughput path is ``generate_dataset_native``: frames are drawn on the device (Philox keyed
+by seed and GLOBAL frame index), processed in large batches by the fused HIP pipeline, sharded as
+contiguous frame ranges over the ranks of a ``torch.distributed`` job, and returned in the stacked
+complex64 schema of the reference's ``run_phase3_dataset_generation.py:135-143`` (plus ``H_mmse``).
+"""
+from __future__ import annotations
+
+import argparse
+from pathlib import Path
+from typing import Dict, List, Tuple
+
+import numpy as np
+
+from . import channel_simulator as _cs
+from . import engine as _engine
+from . import sharding as _sharding
+
+CHANNEL_NAMES = ("EPA", "EVA", "ETU")
+
+
+def _geometry_from_config(config) -> _engine.Geometry:
+    o, m = config['ofdm'], config['mimo']
+    return _engine.Geometry(fft_size=int(o['fft_size']), cp_length=int(o['cp_length']), num_symbols=int(o['num_symbols']),
+                            useful_subcarriers=int(o['useful_subcarriers']),
+                            subcarrier_spacing=float(o['subcarrier_spacing']), num_tx=int(m['num_tx_antennas']),
+                            num_rx=int(m['num_rx_antennas']))
+
+
+class ChannelEstimationDataset:
+    """Dataset generator for channel estimation (reference src/dataset_generator.py:23-180)."""
+
+    def __init__(self, config: Dict):
+        self.config = config
+        self.ofdm_config = config['ofdm']
+        self.mimo_config = config['mimo']
+        self.channel_config = config['channel']
+        self.dataset_config = config.get('dataset', {})
+
+    def generate_sample(self, channel_type: str, doppler_hz: float, snr_db: float, pilot_density: float) -> Dict:
+        """One frame: simulate_transmission + LSEstimator('linear') in ONE fused launch (:34-89)."""
+        geom = _geometry_from_config(self.config)
+        S, T, R, nsc = geom.num_symbols, geom.num_tx, geom.num_rx, geom.num_sc
+        cm = _cs.ChannelModel(channel_type, doppler_hz, self.channel_config['carrier_freq'],
+                              geom.fft_size * geom.subcarrier_spacing)
+        pattern = _cs.PilotPattern(nsc, S, pilot_density)                            # same draw order as
+        P = len(pattern.pilot_indices)                                               # simulate_transmission
+        u_pilot = np.random.random_sample(P)
+        u_data = np.random.random_sample(S * nsc - P)
+        ua, up = cm._draw_oscillators(T, R)
+        n_re = np.random.randn(S, R, nsc)
+        n_im = np.random.randn(S, R, nsc)
+        eng = _engine.get_engine(geom)
+        slot = eng.pattern_slot(pattern.pilot_indices, "linear")
+        out = eng.run_frames(_engine.make_descs(cm.model_type, doppler_hz, snr_db, slot, n=1),
+                             injected={"u_sym": np.concatenate([u_pilot, u_data])[None], "u_angle": ua[None],
+                                       "u_phase": up[None], "n_re": n_re[None], "n_im": n_im[None]},
+                             outputs=("tx", "rx", "H", "H_ls"))
+        c128 = lambda t: t[0].cpu().numpy().astype(np.complex128)
+        return {
+            'rx_symbols': c128(out["rx"]), 'tx_symbols': c128(out["tx"]), 'H_ls': c128(out["H_ls"]),
+            'H_true': c128(out["H"]), 'pilot_mask': pattern.pilot_mask, 'snr_db': snr_db,
+            'channel_type': channel_type, 'doppler_hz': doppler_hz, 'pilot_density': pilot_density,
+        }
+
+    def generate_dataset(self, num_samples: int, split: str = 'train') -> List[Dict]:
+        """The reference's per-frame loop, including its RNG consumption (:91-127)."""
+        dataset = []
+        channel_types = self.channel_config['models']
+        doppler_values = self.channel_config['doppler_hz']
+        snr_values = self.config['simulation']['snr_range']
+        pilot_densities = self.config['pilots']['density']
+        print(f"Generating {split} dataset with {num_samples} samples...")
+        for i in range(num_samples):
+            channel_type = np.random.choice(channel_types)
+            doppler = np.random.choice(doppler_values)
+            snr = np.random.choice(snr_values)
+            pilot_density = np.random.choice(pilot_densities)
+            try:
+                dataset.append(self.generate_sample(channel_type, doppler, snr, pilot_density))
+            except Exception as e:                                                   # printed and skipped (:123-125)
+                print(f"Warning: Failed to generate sample {i}: {e}")
+                continue
+        return dataset
+
+    # ---- native batch path ------------------------------------------------------------------------
+    def generate_dataset_native(self, num_samples: int, seed: int = 42, rank: int = 0, world: int = 1,
+                                batch_frames: int = 4096, pattern_group: int = 1024, with_mmse: bool = True,
+                                channel_types=None, doppler_values=None, snr_values=None, pilot_densities=None,
+                                to_numpy: bool = True) -> Dict:
+        """Frames [begin, end) of this rank out of ``num_samples``, on the device RNG.
+
+        Per-frame parameters are counter-based choices (``sharding.frame_choices``) from the same value
+        lists the reference samples from; one pilot pattern (legacy shuffle seeded by seed, density,
+        group) is shared by each group of ``pattern_group`` consecutive global frames.  Returns the
+        stacked record of ``run_phase3_dataset_generation.py:193-205`` plus ``H_mmse``, ``frame_index``
+        and the fused ``metrics``.
+        """
+        import torch
+        geom = _geometry_from_config(self.config)
+        eng = _engine.get_engine(geom)
+        S, T, R, nsc, G = geom.num_symbols, geom.num_tx, geom.num_rx, geom.num_sc, geom.grid
+        channel_types = list(channel_types or self.channel_config['models'])
+        doppler_values = list(doppler_values or self.channel_config['doppler_hz'])
+        snr_values = list(snr_values or self.config['simulation']['snr_range'])
+        pilot_densities = list(pilot_densities or self.config['pilots']['density'])
+        begin, end = _sharding.shard_range(num_samples, rank, world)
+        n = end - begin
+        idx = np.arange(begin, end, dtype=np.int64)
+        ci, di, si, pi = _sharding.frame_choices(seed, idx, (len(channel_types), len(doppler_values),
+                                                             len(snr_values), len(pilot_densities)))
+        ctype = np.asarray([_engine.channel_code(c) for c in channel_types], dtype=np.int32)[ci]
+        fd = np.asarray(doppler_values, dtype=np.float32)[di]
+        snr = np.asarray(snr_values, dtype=np.float32)[si]
+        dens = np.asarray(pilot_densities, dtype=np.float64)[pi]
+        group = idx // pattern_group
+        slots = np.empty(n, dtype=np.int32)
+        for key in sorted(set(zip(pi.tolist(), group.tolist()))):
+            d = float(pilot_densities[key[0]])
+            rs = np.random.RandomState((int(seed) * 1000003 + key[1] * 101 + key[0]) % (2**32))
+            perm = np.arange(G)
+            rs.shuffle(perm)                                                         # PilotPattern's algorithm (:227-229)
+            pil = np.sort(perm[: int(G * d)])
+            slots[(pi == key[0]) & (group == key[1])] = eng.pattern_slot(pil, "linear")
+        names = ["tx", "rx", "H", "H_ls", "pilot_mask", "metrics"] + (["H_mmse"] if with_mmse else [])
+        chunks = {k: [] for k in names}
+        for b0 in range(0, n, batch_frames):
+            b1 = min(n, b0 + batch_frames)
+            descs = _engine.make_descs(ctype[b0:b1], fd[b0:b1], snr[b0:b1], slots[b0:b1], n=b1 - b0)
+            out = eng.run_frames(descs, seed=seed, frame_offset=int(begin + b0), outputs=names)
+            for k in names:
+                chunks[k].append(out[k].cpu() if to_numpy else out[k])
+        cat = {k: (torch.cat(v) if v else torch.empty(0)) for k, v in chunks.items()}
+        conv = (lambda t: t.numpy()) if to_numpy else (lambda t: t)
+        rec = {
+            'rx_symbols': conv(cat["rx"]), 'tx_symbols': conv(cat["tx"]), 'H_ls': conv(cat["H_ls"]),
+            'H_true': conv(cat["H"]), 'pilot_mask': conv(cat["pilot_mask"].to(torch.float32)),
+            'snr_db': snr.astype(np.float32), 'channel_type': np.asarray(CHANNEL_NAMES)[ctype].astype('U3'),
+            'doppler_hz': fd.astype(np.float32), 'pilot_density': dens.astype(np.float32),
+            'frame_index': idx, 'metrics': conv(cat["metrics"]),
+        }
+        if with_mmse:
+            rec['H_mmse'] = conv(cat["H_mmse"])
+        return rec
+
+    def save_dataset(self, dataset, filepath: str, format: str = 'npz'):
+        """'npz' (np.savez_compressed of the stacked samples) or 'h5' (:129-180).  Accepts the reference's
+        list-of-samples or the stacked dict of ``generate_dataset_native``."""
+        if format not in ('npz', 'h5'):
+            raise ValueError(f"Unknown format: {format}")
+        keys = ('rx_symbols', 'tx_symbols', 'H_ls', 'H_true', 'pilot_mask', 'snr_db', 'channel_type', 'doppler_hz',
+                'pilot_density')
+        if isinstance(dataset, dict):
+            stacked = dict(dataset)
+        else:
+            stacked = {k: (np.stack([s[k] for s in dataset]) if k in keys[:5] else np.array([s[k] for s in dataset]))
+                       for k in keys}
+        if format == 'npz':
+            np.savez_compressed(filepath, **stacked)
+        else:
+            import h5py                                                              # raises ImportError if absent
+            with h5py.File(filepath, 'w') as f:
+                for k, v in stacked.items():
+                    f.create_dataset(k, data=(np.asarray(v, dtype='S10') if k == 'channel_type' else v))
+        print(f"Dataset saved to {filepath}")
+
+
+def prepare_ml_inputs(sample: Dict, normalize: bool = True) -> Tuple[np.ndarray, np.ndarray]:
+    """(inputs [S,nsc,5], targets [S,nsc,2]) of the first rx/tx pair (reference src/dataset_generator.py:183-227)."""
+    rx = np.asarray(sample['rx_symbols'])[:, 0, :]
+    H_ls = np.asarray(sample['H_ls'])[:, 0, 0, :]
+    mask = np.asarray(sample['pilot_mask']).astype(float)
+    ri = lambda z: np.stack([z.real, z.imag], axis=-1)
+    inputs = np.concatenate([ri(rx), ri(H_ls), mask[..., np.newaxis]], axis=-1)
+    targets = ri(np.asarray(sample['H_true'])[:, 0, 0, :])
+    if normalize:
+        inputs[..., :4] = inputs[..., :4] / (np.std(inputs[..., :4]) + 1e-8)
+        targets = targets / (np.std(targets) + 1e-8)
+    return inputs, targets
+
+
+def main():
+    """CLI with the reference's flags (src/dataset_generator.py:230-315) plus --native."""
+    import yaml
+    parser = argparse.ArgumentParser(description='Generate channel estimation dataset')
+    parser.add_argument('--config', type=str, default='configs/experiment_config.yaml')
+    parser.add_argument('--output-dir', type=str, default='data')
+    parser.add_argument('--train-samples', type=int, default=None)
+    parser.add_argument('--val-samples', type=int, default=None)
+    parser.add_argument('--test-samples', type=int, default=None)
+    parser.add_argument('--format', type=str, default='npz', choices=['npz', 'h5'])
+    parser.add_argument('--seed', type=int, default=42)
+    parser.add_argument('--native', action='store_true', help='device RNG + batched pipeline instead of the np.random replay')
+    args = parser.parse_args()
+    import random
+    import torch
+    random.seed(args.seed); np.random.seed(args.seed); torch.manual_seed(args.seed)      # utils.set_seed
+    with open(args.config, 'r') as f:
+        config = yaml.safe_load(f)
+    for k, v in (('train_samples', args.train_samples), ('val_samples', args.val_samples), ('test_samples', args.test_samples)):
+        if v is not None:
+            config['dataset'][k] = v
+    out_dir = Path(args.output_dir)
+    out_dir.mkdir(parents=True, exist_ok=True)
+    gen = ChannelEstimationDataset(config)
+    for j, split in enumerate(('train', 'val', 'test')):
+        n = config['dataset'][f'{split}_samples']
+        ds = gen.generate_dataset_native(n, seed=args.seed + j) if args.native else gen.generate_dataset(n, split)
+        gen.save_dataset(ds, out_dir / f'{split}.{args.format}', format=args.format)
+    print("Dataset generation completed!")
+
+
+if __name__ == '__main__':
+    main()

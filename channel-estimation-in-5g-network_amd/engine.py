@@ -275,6 +275,46 @@ class Engine:
                 "chest_estimate_batch")
         return out
 
+    # ---- full-covariance MMSE (MFMA path) -----------------------------------------------------------------
+    def mmse_full_prepare(self, covariance, snr_db):
+        """W = R (R + sigma^2 I)^-1 with sigma^2 = 10^(-snr/10), float64 on the device; returns W [P,P] complex64."""
+        cov = self._dev(covariance, torch.complex128)
+        if cov.dim() != 2 or cov.shape[0] != cov.shape[1]:
+            raise ValueError("channel_covariance must be a square P x P matrix")
+        P = cov.shape[0]
+        W = self.empty_c64(P, P)
+        nbytes = N.lib().chest_mmse_full_workspace_bytes(P)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        N.check(N.lib().chest_mmse_full_prepare(self._h, self._stream(), P, cov.data_ptr(), float(snr_db), W.data_ptr(),
+                                                ws.data_ptr(), nbytes), "chest_mmse_full_prepare")
+        torch.cuda.current_stream(self.device).synchronize()       # ws is freed on return
+        return W
+
+    def mmse_full_apply(self, rx4d, tx_pilots, slot, W):
+        g = self.geom
+        rx = self._c64(rx4d)
+        if rx.dim() == 4:
+            rx = rx.unsqueeze(0)
+        B = rx.shape[0]
+        if tuple(rx.shape[1:]) != (g.num_symbols, g.num_rx, g.num_tx, g.num_sc):
+            raise ValueError("rx_symbols must be (S,R,T,nsc) for this engine geometry")
+        tp = self._c64(tx_pilots)
+        P = self.num_pilots(slot)
+        if tuple(W.shape) != (P, P):
+            raise ValueError(f"W must be [{P}, {P}] for this pattern")
+        stride = 0 if tp.dim() == 1 else P
+        if tp.numel() != (P if tp.dim() == 1 else B * P):
+            raise ValueError("tx_pilots does not match the pattern's pilot count")
+        M = B * g.num_rx * g.num_tx
+        ppad = (P + 15) // 16 * 16
+        scratch = self.empty_c64(2, M, ppad)
+        out = torch.empty_like(rx)
+        N.check(N.lib().chest_mmse_full_apply(self._h, self._stream(), B, rx.data_ptr(), tp.data_ptr(), stride, int(slot),
+                                              W.contiguous().data_ptr(), scratch.data_ptr(), out.data_ptr()),
+                "chest_mmse_full_apply")
+        torch.cuda.current_stream(self.device).synchronize()       # scratch is freed on return
+        return out
+
     def at_pilots(self, rx_pilots, tx_pilots, mmse=False, snr_db=10.0):
         rx = self._c64(rx_pilots).reshape(-1)
         tx = self._c64(tx_pilots).reshape(-1)

@@ -1,0 +1,64 @@
+"""Frame-range sharding for multi-GPU dataset generation (one process per GPU, RCCL over xGMI).
+
+Frames are independent: every random draw of frame i is a pure function of (seed, i), so a
+contiguous split of [0, total) over the ranks produces exactly the frames a single GPU would
+(reference loop: src/dataset_generator.py:112-125, which is sequential only because it shares one
+global RNG).  There is no collective on the data path; the job ends with ONE gather of the small
+per-frame metadata / metric records.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+def shard_range(total: int, rank: int, world: int):
+    """Contiguous, balanced [begin, end) of rank `rank`; the union over ranks is [0, total)."""
+    if world < 1 or not (0 <= rank < world):
+        raise ValueError(f"bad rank/world {rank}/{world}")
+    base, rem = divmod(int(total), world)
+    begin = rank * base + min(rank, rem)
+    return begin, begin + base + (1 if rank < rem else 0)
+
+
+def _splitmix64(x: np.ndarray) -> np.ndarray:
+    x = (x + np.uint64(0x9E3779B97F4A7C15)) & np.uint64(0xFFFFFFFFFFFFFFFF)
+    z = x
+    z = ((z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)) & np.uint64(0xFFFFFFFFFFFFFFFF)
+    z = ((z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)) & np.uint64(0xFFFFFFFFFFFFFFFF)
+    return z ^ (z >> np.uint64(31))
+
+
+def frame_choices(seed: int, frame_index: np.ndarray, num_options):
+    """Counter-based replacement of the reference's four ``np.random.choice`` calls per frame
+    (src/dataset_generator.py:114-117): option index k of frame i = hash(seed, i, k) mod len(options_k).
+    Deterministic per global frame index, hence invariant to the sharding."""
+    fi = np.asarray(frame_index, dtype=np.uint64)
+    out = []
+    with np.errstate(over="ignore"):
+        for k, n in enumerate(num_options):
+            h = _splitmix64(fi * np.uint64(4) + np.uint64(k) + _splitmix64(np.asarray([seed], dtype=np.uint64)))
+            out.append((h % np.uint64(n)).astype(np.int64))
+    return out
+
+
+def gather_records(local: "np.ndarray", group=None):
+    """The job's single collective: all ranks' per-frame records (float32 [n_local, C]), concatenated in
+    rank order on every rank.  Works on CPU (gloo) and GPU (nccl = RCCL) process groups."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return np.asarray(local)
+    world = dist.get_world_size(group)
+    backend = dist.get_backend(group)
+    dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
+    t = torch.as_tensor(np.ascontiguousarray(local), dtype=torch.float32, device=dev)
+    n = torch.tensor([t.shape[0]], dtype=torch.int64, device=dev)
+    counts = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(counts, n, group=group)
+    counts = [int(c.item()) for c in counts]
+    width = t.shape[1] if t.dim() == 2 else 1
+    pad = torch.zeros((max(counts), width), dtype=torch.float32, device=dev)
+    pad[: t.shape[0]] = t.reshape(-1, width)
+    parts = [torch.zeros_like(pad) for _ in range(world)]
+    dist.all_gather(parts, pad, group=group)
+    return torch.cat([p[:c] for p, c in zip(parts, counts)]).cpu().numpy()
