@@ -157,6 +157,12 @@ int chest_create(const chest_config* cfg, chest_ctx** out) {
         chest_destroy(ctx);
         return CHEST_EHIP;
     }
+    if (hipMalloc((void**)&ctx->d_fp, sizeof(FrameParams)) != hipSuccess ||
+        hipMemcpy(ctx->d_fp, &ctx->fp, sizeof(FrameParams), hipMemcpyHostToDevice) != hipSuccess) {
+        set_error("parameter block upload failed");
+        chest_destroy(ctx);
+        return CHEST_EHIP;
+    }
     const int N = cfg->fft_size;
     if ((N & (N - 1)) == 0) {                                    // FFT twiddles exp(-2 pi j n/N) from float64
         std::vector<float2> tw(N);
@@ -185,6 +191,7 @@ void chest_destroy(chest_ctx* ctx) {
     if (ctx->d_status) (void)hipFree(ctx->d_status);
     if (ctx->d_twiddle) (void)hipFree(ctx->d_twiddle);
     if (ctx->d_gram) (void)hipFree(ctx->d_gram);
+    if (ctx->d_fp) (void)hipFree(ctx->d_fp);
     delete ctx;
 }
 

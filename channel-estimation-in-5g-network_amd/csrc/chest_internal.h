@@ -66,6 +66,7 @@ struct chest_ctx {
     int32_t* d_status = nullptr;   // device error word (bad descriptor seen by a kernel)
     float2* d_twiddle = nullptr;   // FFT twiddles exp(-2 pi j n/N), n < N (power-of-two N only)
     float2* d_gram = nullptr;      // [3][KT][KT] Gram matrices of the tap twiddles over the used bins
+    chest::FrameParams* d_fp = nullptr;   // device copy of fp (kernels read it through uniform scalar loads)
 };
 
 namespace chest {

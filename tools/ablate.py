@@ -42,6 +42,21 @@ cases = {
     "metrics only": ("metrics",),
 }
 full = eng.run_frames(d_dev, outputs=ALL)
+# same-box calibration: flat fill of the same number of bytes (HBM write ceiling of THIS box)
+nbytes = sum(full[k].numel() * full[k].element_size() for k in ("tx", "rx", "H", "H_ls", "H_mmse"))
+cal = torch.empty(nbytes // 4, dtype=torch.float32, device=eng.device)
+for _ in range(2):
+    cal.fill_(1.0)
+torch.cuda.synchronize()
+a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+a.record()
+for _ in range(5):
+    cal.fill_(1.0)
+b.record()
+torch.cuda.synchronize()
+ms = a.elapsed_time(b) / 5
+print(f"{'flat fill of the same bytes':28s} {ms:8.3f} ms   {nbytes / ms * 1e-9:8.3f} TB/s", flush=True)
+del cal
 for name, outs in cases.items():
     out = {k: full[k] for k in outs}
     for _ in range(2):
