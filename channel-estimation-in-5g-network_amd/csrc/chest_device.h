@@ -19,8 +19,15 @@ struct u32x4 { uint32_t x, y, z, w; };
 
 __device__ __forceinline__ u32x4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
                                                 uint32_t k0, uint32_t k1) {
+#ifndef CHEST_PHILOX_ROUNDS
+#define CHEST_PHILOX_ROUNDS 10
+#endif
+#ifdef CHEST_FAKE_RNG      // timing experiments only: NOT a usable generator
+    const uint32_t h = (c0 * 2654435761u) ^ (c1 * 40503u) ^ c2 ^ k0;
+    return {h, h * 1664525u + 1013904223u, h ^ 0x9E3779B9u, h * 22695477u + 1u};
+#endif
 #pragma unroll
-    for (int i = 0; i < 10; ++i) {
+    for (int i = 0; i < CHEST_PHILOX_ROUNDS; ++i) {
         const uint64_t p0 = (uint64_t)0xD2511F53u * c0;     // one v_mad_u64_u32 gives hi and lo
         const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
         c0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0; c1 = (uint32_t)p1;

@@ -29,11 +29,12 @@ namespace chest {
 // K1: per-frame tap gains and analytic powers
 // ================================================================================================
 __global__ void __launch_bounds__(256)
-taps_kernel(const FrameParams fp, const chest_frame_desc* __restrict__ descs, int npatterns,
+taps_kernel(const FrameParams* __restrict__ fpp, const chest_frame_desc* __restrict__ descs, int npatterns,
             const float2* __restrict__ gram, uint64_t seed, uint64_t frame_offset,
             const float* __restrict__ inj_angle, const float* __restrict__ inj_phase, int inj_paths,
             float* __restrict__ state, int* __restrict__ status) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    const FrameParams& fp = *fpp;                                // device-resident constant block (uniform scalar loads)
     const int b = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
     const int S = fp.S, T = fp.T, R = fp.R;
     const chest_frame_desc fd = descs[b];
@@ -411,11 +412,12 @@ __host__ __device__ inline int frame_tw_stride(int nch) { return nch * 126 + 2; 
 #define CHEST_K2_MINWAVES 1
 #endif
 __global__ void __launch_bounds__(CHEST_K2_BOUNDS, CHEST_K2_MINWAVES)
-frame_kernel(const FrameParams fp, const chest_frame_desc* __restrict__ descs,
+frame_kernel(const FrameParams* __restrict__ fpp, const chest_frame_desc* __restrict__ descs,
              const PatternDev* __restrict__ patterns, int Pmax, uint64_t seed, uint64_t frame_offset,
              const chest_injected inj, const chest_frame_outputs out, const float* __restrict__ state,
              int nch, int* __restrict__ status) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    const FrameParams& fp = *fpp;
     const int b = blockIdx.x, tid = threadIdx.x;
     const int S = fp.S, T = fp.T, R = fp.R, nsc = fp.nsc, G = fp.G;
     const float* rec = state + (size_t)b * frame_state_floats(S, R, T);
@@ -487,7 +489,7 @@ static int launch_k2(chest_ctx* ctx, hipStream_t st, int32_t B, int nch, const c
         CHEST_HIP(hipFuncSetAttribute((const void*)frame_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
         attr = lds2;
     }
-    hipLaunchKernelGGL(frame_kernel, dim3(B), dim3(ctx->block_threads), lds2, st, ctx->fp, descs, ctx->d_patterns,
+    hipLaunchKernelGGL(frame_kernel, dim3(B), dim3(ctx->block_threads), lds2, st, ctx->d_fp, descs, ctx->d_patterns,
                        Pmax, seed, frame_offset, inj, out, workspace, nch, ctx->d_status);
     return CHEST_OK;
 }
@@ -521,7 +523,7 @@ int launch_frames(chest_ctx* ctx, hipStream_t st, int32_t B, const chest_frame_d
         return CHEST_EINVAL;
     }
     const int nch = (fp.nsc + 125) / 126;
-    hipLaunchKernelGGL(taps_kernel, dim3(B), dim3(256), lds1, st, fp, descs, (int)ctx->patterns.size(), ctx->d_gram, seed,
+    hipLaunchKernelGGL(taps_kernel, dim3(B), dim3(256), lds1, st, ctx->d_fp, descs, (int)ctx->patterns.size(), ctx->d_gram, seed,
                        frame_offset, inj_v.u_angle, inj_v.u_phase, inj_v.inj_paths, (float*)workspace, ctx->d_status);
     const int rc = launch_k2(ctx, st, B, nch, descs, Pmax, seed, frame_offset, inj_v, *out, (const float*)workspace);
     if (rc != CHEST_OK) return rc;
