@@ -106,6 +106,9 @@ def main():
     ap.add_argument("--frames", type=int, default=None, help="frames per step per GPU (default: the config's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--with-metrics", action="store_true", help="also produce the fused error sums inside the timed step")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl (= RCCL, one GPU per rank) for real runs; gloo only to rehearse the N>1 control flow with "
+                         "several ranks sharing one GPU")
     args = ap.parse_args()
 
     import torch
@@ -115,10 +118,16 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.dist_backend == "gloo":
+        local = local % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+    coll_dev = torch.device("cuda", local) if args.dist_backend == "nccl" else torch.device("cpu")
 
     E = importlib.import_module(PKG + ".engine")
     T, R, N, cp, U, ct, fd, snr, dens, F = WORKLOADS[args.workload]
@@ -169,15 +178,16 @@ def main():
     m = mse_out
     summ[0], summ[1], summ[2], summ[3] = m[:, 0].sum(), m[:, 1].sum(), m[:, 2].sum(), m[:, 6].sum()
     if world > 1:
-        gathered = [torch.zeros_like(summ) for _ in range(world)]
-        dist.all_gather(gathered, summ)
+        summ_c = summ.to(coll_dev)
+        gathered = [torch.zeros_like(summ_c) for _ in range(world)]
+        dist.all_gather(gathered, summ_c)
         summ = torch.stack(gathered).sum(0)
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     eng.check_status()
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=eng.device)
+        tmax = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
