@@ -207,6 +207,26 @@ class MIMOChannel:
         return _np128(rx[0])
 
 
+def time_domain_link(ofdm_config: OFDMConfig, channel_model: ChannelModel, tx_grids: np.ndarray, num_rx: int) -> Dict:
+    """EXTENSION (no reference counterpart): the true time-domain link.  ``tx_grids`` (num_tx, S, nsc) are
+    OFDM-modulated (IFFT + CP), passed through the time-varying tapped-delay-line channel sample by sample, and
+    demodulated (CP removal + FFT).  Unlike the reference's frequency-domain shortcut this includes ISI/ICI when the
+    channel's delay spread exceeds the CP or the channel varies within a symbol.  Consumes the global ``np.random``
+    stream like ``generate_time_varying_channel``.  Returns dict(rx_grids (num_rx,S,nsc), time_tx, time_rx, h)."""
+    tx_grids = np.asarray(tx_grids)
+    T, S, nsc = tx_grids.shape
+    osys = OFDMSystem(ofdm_config)
+    eng = osys._eng()
+    spl = ofdm_config.fft_size + ofdm_config.cp_length
+    time_tx = eng.ofdm_modulate(tx_grids.reshape(T * S, nsc)).reshape(T, S * spl)
+    ua, up = channel_model._draw_oscillators(T, num_rx)
+    ceng = channel_model._engine_for_rate(T, num_rx)
+    h = ceng.time_varying_channel(channel_model.model_type, channel_model.doppler_hz, S * spl, T, num_rx, ua, up)
+    y = ceng.tdl_apply(time_tx, h, channel_model.model_type)
+    rx = eng.ofdm_demodulate(y.reshape(num_rx * S, spl)).reshape(num_rx, S, nsc)
+    return {'rx_grids': _np128(rx), 'time_tx': _np128(time_tx), 'time_rx': _np128(y), 'h': h, 'u_angle': ua, 'u_phase': up}
+
+
 def simulate_transmission(config: Dict, channel_type: str = 'EPA', doppler_hz: float = 50, snr_db: float = 10,
                           pilot_density: float = 0.1) -> Dict:
     """Complete MIMO-OFDM transmission simulation (reference src/channel_simulator.py:348-421).

@@ -366,4 +366,19 @@ int chest_equalize(chest_ctx* ctx, void* stream, int32_t B, const float* rx, con
     return launch_equalize(ctx, (hipStream_t)stream, B, rx, H, method, out);
 }
 
+int chest_tdl_apply(chest_ctx* ctx, void* stream, int32_t type, int64_t ns, int32_t T, int32_t R, const float* x, const float* h,
+                    float* y) {
+    if (!ctx || ns < 0 || T < 0 || R < 0 || (ns > 0 && (!x || !h || !y))) { set_error("chest_tdl_apply: bad argument"); return CHEST_EINVAL; }
+    return launch_tdl(ctx, (hipStream_t)stream, type, ns, T, R, x, h, y);
+}
+
+int chest_pack_ml_inputs(chest_ctx* ctx, void* stream, int32_t B, const float* rx, const float* H_ls, const float* H_true,
+                         const uint8_t* mask, int32_t normalize, float* inputs, float* targets) {
+    if (!ctx || B < 0 || (B > 0 && (!rx || !H_ls || !H_true || !mask || !inputs || !targets))) {
+        set_error("chest_pack_ml_inputs: bad argument");
+        return CHEST_EINVAL;
+    }
+    return launch_pack_ml(ctx, (hipStream_t)stream, B, rx, H_ls, H_true, mask, normalize, inputs, targets);
+}
+
 }  // extern "C"

@@ -98,4 +98,8 @@ int launch_tv_channel(chest_ctx* ctx, hipStream_t st, int32_t type, float fd, in
 int launch_ofdm(chest_ctx* ctx, hipStream_t st, int32_t n, const float* in, float* out, bool modulate);
 int launch_equalize(chest_ctx* ctx, hipStream_t st, int32_t B, const float* rx, const float* H, int32_t method,
                     float* out);
+int launch_tdl(chest_ctx* ctx, hipStream_t st, int32_t type, int64_t ns, int32_t T, int32_t R, const float* x, const float* h,
+               float* y);
+int launch_pack_ml(chest_ctx* ctx, hipStream_t st, int32_t B, const float* rx, const float* Hls, const float* Htrue,
+                   const uint8_t* mask, int32_t normalize, float* inputs, float* targets);
 }  // namespace chest

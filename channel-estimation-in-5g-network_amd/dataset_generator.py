@@ -186,6 +186,15 @@ def prepare_ml_inputs(sample: Dict, normalize: bool = True) -> Tuple[np.ndarray,
     return inputs, targets
 
 
+def prepare_ml_inputs_batch(dataset: Dict, config: Dict, normalize: bool = True):
+    """``prepare_ml_inputs`` for a stacked dataset (``generate_dataset_native`` output or a loaded .npz) in one GPU
+    launch; returns float32 device tensors (inputs [N,S,nsc,5], targets [N,S,nsc,2])."""
+    eng = _engine.get_engine(_geometry_from_config(config))
+    mask = np.asarray(dataset['pilot_mask']) if not hasattr(dataset['pilot_mask'], 'device') else dataset['pilot_mask']
+    mask = (mask != 0)
+    return eng.pack_ml_inputs(dataset['rx_symbols'], dataset['H_ls'], dataset['H_true'], mask, normalize)
+
+
 def main():
     """CLI with the reference's flags (src/dataset_generator.py:230-315) plus --native."""
     import yaml

@@ -370,6 +370,41 @@ class Engine:
                                                    out.data_ptr()), "chest_time_varying_channel")
         return out
 
+    def tdl_apply(self, time_tx, h, channel_type):
+        """y[r][n] = sum_t sum_l h[n][r][t][d_l] x[t][n-d_l]: time_tx [T][ns], h [ns][R][T][D+1] -> [R][ns]."""
+        x = self._c64(time_tx)
+        hh = self._c64(h)
+        if x.dim() != 2 or hh.dim() != 4 or hh.shape[0] != x.shape[1] or hh.shape[2] != x.shape[0]:
+            raise ValueError("time_tx must be [T, ns] and h [ns, R, T, D+1]")
+        code = channel_code(channel_type)
+        _, d = self.tap_table(code)
+        if hh.shape[3] != int(d.max()) + 1:
+            raise ValueError(f"h has {hh.shape[3]} delay taps, profile {channel_type} needs {int(d.max()) + 1}")
+        ns, R, T = int(hh.shape[0]), int(hh.shape[1]), int(hh.shape[2])
+        y = self.empty_c64(R, ns)
+        N.check(N.lib().chest_tdl_apply(self._h, self._stream(), code, ns, T, R, x.data_ptr(), hh.data_ptr(), y.data_ptr()),
+                "chest_tdl_apply")
+        return y
+
+    def pack_ml_inputs(self, rx, H_ls, H_true, pilot_mask, normalize=True):
+        """Batched prepare_ml_inputs on the GPU: (inputs [B,S,nsc,5], targets [B,S,nsc,2]) float32 device tensors."""
+        g = self.geom
+        rxd, ls, ht = self._c64(rx), self._c64(H_ls), self._c64(H_true)
+        m = self._dev(pilot_mask, torch.uint8)
+        if rxd.dim() == 3:
+            rxd, ls, ht, m = rxd.unsqueeze(0), ls.unsqueeze(0), ht.unsqueeze(0), m.unsqueeze(0)
+        B = rxd.shape[0]
+        if tuple(rxd.shape[1:]) != (g.num_symbols, g.num_rx, g.num_sc) or \
+                tuple(ls.shape) != (B, g.num_symbols, g.num_rx, g.num_tx, g.num_sc) or ls.shape != ht.shape or \
+                tuple(m.shape) != (B, g.num_symbols, g.num_sc):
+            raise ValueError("rx [B,S,R,nsc], H_ls/H_true [B,S,R,T,nsc], pilot_mask [B,S,nsc] expected")
+        inputs = torch.empty(B, g.num_symbols, g.num_sc, 5, dtype=torch.float32, device=self.device)
+        targets = torch.empty(B, g.num_symbols, g.num_sc, 2, dtype=torch.float32, device=self.device)
+        N.check(N.lib().chest_pack_ml_inputs(self._h, self._stream(), B, rxd.data_ptr(), ls.data_ptr(), ht.data_ptr(),
+                                             m.data_ptr(), int(bool(normalize)), inputs.data_ptr(), targets.data_ptr()),
+                "chest_pack_ml_inputs")
+        return inputs, targets
+
     def ofdm_modulate(self, symbols):
         g = self.geom
         s = self._c64(symbols)

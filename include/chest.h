@@ -189,6 +189,20 @@ int chest_ofdm_demodulate(chest_ctx* ctx, void* stream, int32_t n, const float* 
 int chest_equalize(chest_ctx* ctx, void* stream, int32_t num_frames, const float* rx, const float* H_est,
                    int32_t method, float* out);
 
+/* Time-domain tapped-delay-line link (no reference counterpart; closes OFDMSystem.modulate -> multipath channel of
+ * ChannelModel.generate_time_varying_channel, src/channel_simulator.py:84-127 -> OFDMSystem.demodulate):
+ * y[r][n] = sum_t sum_l h[n][r][t][d_l] x[t][n - d_l], x [T][num_samples] c64, h [num_samples][R][T][D+1] c64 (the dense
+ * output of chest_time_varying_channel for the same channel_type), y [R][num_samples] c64. */
+int chest_tdl_apply(chest_ctx* ctx, void* stream, int32_t channel_type, int64_t num_samples, int32_t num_tx, int32_t num_rx,
+                    const float* x, const float* h, float* y);
+
+/* prepare_ml_inputs (src/dataset_generator.py:183-227) for a batch: inputs [B][S][nsc][5] f32 = (rx re, rx im, H_ls re,
+ * H_ls im, mask) of the first rx/tx pair, targets [B][S][nsc][2] f32 = H_true of that pair; normalize != 0 divides the four
+ * complex input channels / the targets by their per-frame population std + 1e-8.  rx [B][S][R][nsc], H_ls / H_true
+ * [B][S][R][T][nsc] c64, mask [B][S][nsc] u8. */
+int chest_pack_ml_inputs(chest_ctx* ctx, void* stream, int32_t num_frames, const float* rx, const float* H_ls,
+                         const float* H_true, const uint8_t* mask, int32_t normalize, float* inputs, float* targets);
+
 /* Full-covariance MMSE (MMSEEstimator(channel_covariance=R, estimate_statistics=False), :181-190).
  * prepare: W = R (R + sigma^2 I)^-1 in float64 on the device (blocked Cholesky), stored as c64
  *          W [P][P]; cov is DEVICE complex128 [P][P] (interleaved doubles).
