@@ -57,7 +57,7 @@ def _prep(rx_symbols, pilot_mask, pilot_positions, method):
     mask = np.asarray(pilot_mask.cpu() if _is_tensor(pilot_mask) else pilot_mask, dtype=bool)
     if mask.shape != (S, nsc) or int(mask.sum()) != len(flat) or not mask.reshape(-1)[flat].all():
         raise ValueError("pilot_mask and pilot_positions describe different pilot sets")
-    slot = eng.pattern_slot(flat, method)
+    slot = eng.pattern_slot(flat, method, with_plan=method is not None)
     return eng, slot
 
 
@@ -81,21 +81,32 @@ class LSEstimator:
         like_np = not _is_tensor(h_pilots)
         S, nsc = grid_shape
         eng = _engine_for((S, 1, 1, nsc))
-        slot = eng.pattern_slot(_pilot_flat(pilot_positions, nsc), self.interpolation_method)
+        cubic = self.interpolation_method == 'cubic'
+        slot = eng.pattern_slot(_pilot_flat(pilot_positions, nsc), None if cubic else self.interpolation_method,
+                                with_plan=not cubic)
         # plant the pilot values on a grid with unit pilots: y/(1+1e-12) == y to float32 rounding
         flat = _pilot_flat(pilot_positions, nsc)
         hp = eng._c64(h_pilots).reshape(-1)
         grid = torch.zeros(S * nsc, dtype=torch.complex64, device=eng.device)
         grid[torch.from_numpy(flat).to(eng.device)] = hp
         ones = torch.ones(len(flat), dtype=torch.complex64, device=eng.device)
-        out = eng.estimate(grid.reshape(1, S, 1, 1, nsc), ones, slot, mmse=False)
+        if cubic:
+            out = eng.estimate_dense(grid.reshape(1, S, 1, 1, nsc), ones, slot, eng.cubic_operator(flat))
+        else:
+            out = eng.estimate(grid.reshape(1, S, 1, 1, nsc), ones, slot, mmse=False)
         return _back(out[0, :, 0, 0, :], like_np)
 
     def estimate(self, rx_symbols, tx_pilots, pilot_mask, pilot_positions: Tuple):
         """Complete LS estimation with interpolation for every (rx, tx) grid (:83-117)."""
         like_np = not _is_tensor(rx_symbols)
-        eng, slot = _prep(rx_symbols, pilot_mask, pilot_positions, self.interpolation_method)
-        out = eng.estimate(rx_symbols, tx_pilots, slot, mmse=False)
+        if self.interpolation_method == 'cubic':
+            # Clough-Tocher is a dense linear operator on the pilot values: MFMA GEMM instead of a 3-point gather
+            eng, slot = _prep(rx_symbols, pilot_mask, pilot_positions, None)
+            A = eng.cubic_operator(_pilot_flat(pilot_positions, rx_symbols.shape[-1]))
+            out = eng.estimate_dense(rx_symbols, tx_pilots, slot, A)
+        else:
+            eng, slot = _prep(rx_symbols, pilot_mask, pilot_positions, self.interpolation_method)
+            out = eng.estimate(rx_symbols, tx_pilots, slot, mmse=False)
         return _back(out[0], like_np)
 
 

@@ -159,6 +159,51 @@ interp_from_pilots_kernel(int S, int R, int T, int nsc, int Ppad, const PatternD
     }
 }
 
+// Dense interpolation operator (Clough-Tocher 'cubic', interp_plan.cubic_operator): H[m][g] = sum_p A[g][p] h[m][p],
+// A real [G][P], h complex [M][Ppad].  Rows of the MFMA tile = grids m, columns = resource elements g, so that the
+// 32 lanes of a C/D register hold consecutive subcarriers of one grid row (coalesced 256-B stores into [B][S][R][T][nsc]).
+__global__ void __launch_bounds__(256)
+dense_interp_kernel(int S, int R, int T, int nsc, int P, int Ppad, int M, const float* __restrict__ A,
+                    const float2* __restrict__ h, float2* __restrict__ H_est) {
+    __shared__ float2 Hs[GB_M * GB_LD];        // [m][k]
+    __shared__ float As[GB_N * GB_LD];         // [g][k]
+    const int G = S * nsc;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int m0 = blockIdx.y * GB_M, g0 = blockIdx.x * GB_N;
+    const int wm = (wave & 1) * 32, wg = (wave >> 1) * 32;
+    f32x16 cre = {0}, cim = {0};
+    const int lrow = tid >> 2, lk = (tid & 3) * 4;
+    for (int k0 = 0; k0 < P; k0 += GB_K) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int k = k0 + lk + q;
+            Hs[lrow * GB_LD + lk + q] = (m0 + lrow < M && k < Ppad) ? h[(size_t)(m0 + lrow) * Ppad + k] : make_float2(0.f, 0.f);
+            As[lrow * GB_LD + lk + q] = (g0 + lrow < G && k < P) ? A[(size_t)(g0 + lrow) * P + k] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < GB_K; kk += 2) {
+            const float2 hv = Hs[(wm + (lane & 31)) * GB_LD + kk + (lane >> 5)];      // A operand: rows m
+            const float av = As[(wg + (lane & 31)) * GB_LD + kk + (lane >> 5)];       // B operand: columns g
+            cre = __builtin_amdgcn_mfma_f32_32x32x2f32(hv.x, av, cre, 0, 0, 0);
+            cim = __builtin_amdgcn_mfma_f32_32x32x2f32(hv.y, av, cim, 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    const int g = g0 + wg + (lane & 31);
+    if (g < G) {
+        const int s = g / nsc, k = g - s * nsc;
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int m = m0 + wm + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+            if (m < M) {
+                const int t = m % T, r = (m / T) % R, b = m / (T * R);
+                H_est[(((size_t)b * S + s) * R + r) * T * nsc + (size_t)t * nsc + k] = make_float2(cre[reg], cim[reg]);
+            }
+        }
+    }
+}
+
 static inline int pad16(int p) { return (p + 15) & ~15; }
 
 }  // namespace chest
@@ -224,6 +269,29 @@ int chest_mmse_full_apply(chest_ctx* ctx, void* stream, int32_t B, const float* 
         CHEST_HIP(hipFuncSetAttribute((const void*)interp_from_pilots_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(interp_from_pilots_kernel, dim3(M), dim3(256), lds, st, f.S, f.R, f.T, f.nsc, Ppad, ctx->d_patterns,
                        slot, h_out, (float2*)H_est);
+    CHEST_HIP(hipGetLastError());
+    return CHEST_OK;
+}
+
+int chest_estimate_dense(chest_ctx* ctx, void* stream, int32_t B, const float* rx4d, const float* tx_pilots,
+                         int32_t pilot_stride, int32_t slot, const float* A, float* h_scratch, float* H_est) {
+    if (!ctx || B < 0 || (B > 0 && (!rx4d || !tx_pilots || !A || !h_scratch || !H_est))) {
+        set_error("chest_estimate_dense: bad argument");
+        return CHEST_EINVAL;
+    }
+    if (B == 0) return CHEST_OK;
+    if (slot < 0 || slot >= (int)ctx->patterns.size() || ctx->patterns[slot].dev.slot == nullptr) {
+        set_error("pattern slot %d is not set", slot);
+        return CHEST_ESTATE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const auto& f = ctx->fp;
+    const PatternDev& pd = ctx->patterns[slot].dev;
+    const int P = pd.P, Ppad = pad16(P), M = B * f.R * f.T;
+    hipLaunchKernelGGL(gather_ls_kernel, dim3(M), dim3(256), 0, st, f.S, f.R, f.T, f.nsc, P, Ppad, pd.pilot_idx,
+                       (const float2*)rx4d, (const float2*)tx_pilots, pilot_stride, (float2*)h_scratch);
+    hipLaunchKernelGGL(dense_interp_kernel, dim3((f.G + GB_N - 1) / GB_N, (M + GB_M - 1) / GB_M), dim3(256), 0, st, f.S, f.R,
+                       f.T, f.nsc, P, Ppad, M, A, (const float2*)h_scratch, (float2*)H_est);
     CHEST_HIP(hipGetLastError());
     return CHEST_OK;
 }

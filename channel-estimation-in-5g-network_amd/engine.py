@@ -89,6 +89,7 @@ class Engine:
         self._next_slot = 0
         self.max_cached_patterns = 4096
         self._workspace = None
+        self._dense = {}          # pattern key -> dense interpolation operator on the device
         nsc = C.c_int32()
         N.check(N.lib().chest_get_used_indices(self._h, C.byref(nsc), None))
         assert nsc.value == geometry.num_sc
@@ -312,6 +313,46 @@ class Engine:
         N.check(N.lib().chest_mmse_full_apply(self._h, self._stream(), B, rx.data_ptr(), tp.data_ptr(), stride, int(slot),
                                               W.contiguous().data_ptr(), scratch.data_ptr(), out.data_ptr()),
                 "chest_mmse_full_apply")
+        torch.cuda.current_stream(self.device).synchronize()       # scratch is freed on return
+        return out
+
+    def cubic_operator(self, pilot_idx):
+        """Device copy of the dense Clough-Tocher operator of a pattern (cached, least recently used of 4 dropped)."""
+        key = interp_plan.pattern_key(pilot_idx, "cubic")
+        hit = self._dense.get(key)
+        if hit is None:
+            S, nsc = self.geom.num_symbols, self.geom.num_sc
+            ps, pk = np.unravel_index(np.asarray(pilot_idx, dtype=np.int64), (S, nsc))
+            hit = torch.from_numpy(interp_plan.cubic_operator(ps, pk, S, nsc)).to(self.device)
+            if len(self._dense) >= 4:
+                self._dense.pop(next(iter(self._dense)))
+        else:
+            self._dense.pop(key)
+        self._dense[key] = hit
+        return hit
+
+    def estimate_dense(self, rx4d, tx_pilots, slot, A):
+        """LS pilot division + dense interpolation operator A [G, P] (LSEstimator('cubic'))."""
+        g = self.geom
+        rx = self._c64(rx4d)
+        if rx.dim() == 4:
+            rx = rx.unsqueeze(0)
+        B = rx.shape[0]
+        if tuple(rx.shape[1:]) != (g.num_symbols, g.num_rx, g.num_tx, g.num_sc):
+            raise ValueError("rx_symbols must be (S,R,T,nsc) for this engine geometry")
+        P = self.num_pilots(slot)
+        if tuple(A.shape) != (g.grid, P) or A.dtype != torch.float32:
+            raise ValueError(f"A must be float32 [{g.grid}, {P}]")
+        tp = self._c64(tx_pilots)
+        stride = 0 if tp.dim() == 1 else P
+        if tp.numel() != (P if tp.dim() == 1 else B * P):
+            raise ValueError("tx_pilots does not match the pattern's pilot count")
+        M = B * g.num_rx * g.num_tx
+        scratch = self.empty_c64(M, (P + 15) // 16 * 16)
+        out = torch.empty_like(rx)
+        N.check(N.lib().chest_estimate_dense(self._h, self._stream(), B, rx.data_ptr(), tp.data_ptr(), stride, int(slot),
+                                             A.contiguous().data_ptr(), scratch.data_ptr(), out.data_ptr()),
+                "chest_estimate_dense")
         torch.cuda.current_stream(self.device).synchronize()       # scratch is freed on return
         return out
 

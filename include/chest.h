@@ -215,6 +215,13 @@ int chest_mmse_full_apply(chest_ctx* ctx, void* stream, int32_t num_frames, cons
                           const float* tx_pilots, int32_t pilot_stride, int32_t pattern_slot,
                           const float* W, float* h_scratch /*[2][B*R*T][roundup16(P)] c64*/, float* H_est);
 
+/* LSEstimator('cubic').estimate (src/baseline_estimators.py:65-79 with method='cubic' = scipy Clough-Tocher): the
+ * interpolation is a dense linear operator A [G][P] float32 (DEVICE; built on the host once per pattern from scipy's own
+ * interpolator, see interp_plan.cubic_operator), applied to the LS pilot estimates of all B*R*T grids as a real x complex
+ * GEMM on the f32 MFMA pipe.  h_scratch: DEVICE [B*R*T][roundup16(P)] c64. */
+int chest_estimate_dense(chest_ctx* ctx, void* stream, int32_t num_frames, const float* rx4d, const float* tx_pilots,
+                         int32_t pilot_stride, int32_t pattern_slot, const float* A, float* h_scratch, float* H_est);
+
 #ifdef __cplusplus
 }
 #endif

@@ -38,8 +38,6 @@ def test_plan_reproduces_griddata(name, S, nsc, method):
 
 
 def test_plan_errors():
-    with pytest.raises(NotImplementedError):
-        ip.build_plan([0, 1, 2], [0, 5, 9], 14, 71, "cubic")
     with pytest.raises(ValueError):
         ip.build_plan([0, 1, 2], [0, 5, 9], 14, 71, "bogus")
     from scipy.spatial import QhullError
@@ -141,3 +139,18 @@ def test_prepare_ml_inputs_matches_reference_semantics():
     assert np.array_equal(x[..., 0], g["rx"][:, 0, :].real) and np.array_equal(y[..., 1], g["H"][:, 0, 0, :].imag)
     xn, yn = dg.prepare_ml_inputs(sample, normalize=True)
     assert np.std(xn[..., :4]) == pytest.approx(1.0, rel=1e-6) and np.std(yn) == pytest.approx(1.0, rel=1e-6)
+
+
+def test_cubic_operator_reproduces_griddata_cubic():
+    g = dict(np.load(os.path.join(GOLDEN, "cubic_small_2x2_eva.npz")))
+    S, nsc = 14, 71
+    ps, pk = np.unravel_index(g["pilot_indices"], (S, nsc))
+    A = ip.cubic_operator(ps, pk, S, nsc)
+    assert A.shape == (S * nsc, len(ps)) and A.dtype == np.float32
+    mask = np.zeros((S, nsc), bool); mask[ps, pk] = True
+    h_p = g["rx"][:, 0, :][mask] / (g["pilot_symbols"] + 1e-12)
+    got = (A.astype(np.float64) @ h_p).reshape(S, nsc)
+    assert np.max(np.abs(got - g["H_cubic"][:, 0, :])) / np.max(np.abs(g["H_cubic"])) < 1e-5
+    assert np.max(np.abs(got[ps, pk] - h_p)) < 1e-5 * np.max(np.abs(h_p))        # exact at the pilots
+    with pytest.raises(ValueError):
+        ip.build_plan(ps, pk, S, nsc, "cubic")                                   # cubic has no 3-point plan

@@ -251,16 +251,43 @@ def dataset_kat(ref_root, out_dir):
                                       r["num_pilots"]) for r in rec])
 
 
+def cubic_cases(ref, out_dir):
+    """LSEstimator('cubic') (scipy Clough-Tocher) outputs of the reference: self-contained fixtures cubic_*.npz."""
+    cs, be = ref
+    for name, seed, U, T, R, ct, fd, snr, dens in (("cubic_small_2x2_eva", 1201, 72, 2, 2, "EVA", 111.1, 10, 0.10),
+                                                    ("cubic_small_siso_etu", 1202, 72, 1, 1, "ETU", 200.0, 20, 0.05),
+                                                    ("cubic_full_2x2_eva", 1203, 600, 2, 2, "EVA", 50.0, 15, 0.10)):
+        cfg = make_cfg(1024, 72, U, T, R)
+        np.random.seed(seed)
+        sim = cs.simulate_transmission(cfg, ct, fd, snr, dens)
+        pp = sim["pilot_pattern"]
+        rx4 = np.repeat(sim["rx_symbols"][:, :, None, :], T, axis=2)
+        H_c = be.LSEstimator("cubic").estimate(rx4, sim["pilot_symbols"], pp.pilot_mask, pp.pilot_positions)
+        o_c = O.ls_estimate(rx4, sim["pilot_symbols"], pp.pilot_mask, pp.pilot_positions, "cubic")
+        assert rel(o_c, H_c) < TOL, name
+        for t in range(1, T):
+            assert np.array_equal(H_c[:, :, t, :], H_c[:, :, 0, :])
+        np.savez_compressed(os.path.join(out_dir, name + ".npz"), useful_subcarriers=U, num_tx=T, num_rx=R, seed=seed,
+                            pilot_indices=pp.pilot_indices.astype(np.int32), rx=sim["rx_symbols"],
+                            pilot_symbols=sim["pilot_symbols"], H_cubic=H_c[:, :, 0, :],
+                            nmse_db_cubic=be.evaluate_estimator(sim["channel"], H_c)["nmse_db"])
+        print(f"{name:34s} ok  {os.path.getsize(os.path.join(out_dir, name + '.npz')) / 1024:.0f} KiB")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reference", default="/root/reference")
     ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden"))
+    ap.add_argument("--only-cubic", action="store_true", help="write only the cubic_*.npz fixtures")
     args = ap.parse_args()
     sys.path.insert(0, os.path.join(args.reference, "src"))
     import baseline_estimators as be
     import channel_simulator as cs
     ref = (cs, be)
     os.makedirs(args.out, exist_ok=True)
+    cubic_cases(ref, args.out)
+    if args.only_cubic:
+        return
 
     # 1. reduced grid: N=1024/cp=72 keeps realistic tap delays; U=72 -> nsc 71, S*nsc 994.
     small = [
