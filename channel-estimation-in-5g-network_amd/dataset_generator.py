@@ -94,7 +94,7 @@ class ChannelEstimationDataset:
     def generate_dataset_native(self, num_samples: int, seed: int = 42, rank: int = 0, world: int = 1,
                                 batch_frames: int = 4096, pattern_group: int = 1024, with_mmse: bool = True,
                                 channel_types=None, doppler_values=None, snr_values=None, pilot_densities=None,
-                                to_numpy: bool = True) -> Dict:
+                                to_numpy: bool = True, _range=None) -> Dict:
         """Frames [begin, end) of this rank out of ``num_samples``, on the device RNG.
 
         Per-frame parameters are counter-based choices (``sharding.frame_choices``) from the same value
@@ -111,7 +111,7 @@ class ChannelEstimationDataset:
         doppler_values = list(doppler_values or self.channel_config['doppler_hz'])
         snr_values = list(snr_values or self.config['simulation']['snr_range'])
         pilot_densities = list(pilot_densities or self.config['pilots']['density'])
-        begin, end = _sharding.shard_range(num_samples, rank, world)
+        begin, end = _range if _range is not None else _sharding.shard_range(num_samples, rank, world)
         n = end - begin
         idx = np.arange(begin, end, dtype=np.int64)
         ci, di, si, pi = _sharding.frame_choices(seed, idx, (len(channel_types), len(doppler_values),
@@ -149,6 +149,39 @@ class ChannelEstimationDataset:
         if with_mmse:
             rec['H_mmse'] = conv(cat["H_mmse"])
         return rec
+
+    def generate_dataset_native_to_files(self, num_samples: int, out_dir: str, split: str = 'train', seed: int = 42,
+                                         rank: int = 0, world: int = 1, chunk_frames: int = 4096, **kwargs) -> Dict:
+        """Stream this rank's frame range to chunk files ``{split}_rank{rank:02d}_chunk{id:04d}.npz`` (the reference's
+        ``checkpoints/{split}_chunk_{id:04d}.npz`` scheme, run_phase3_robust.py:99-101, one series per rank) plus a JSON
+        manifest.  Chunks already on disk are skipped: with counter-based RNG a resumed run produces exactly the frames
+        an uninterrupted run would (the reference re-seeds on resume, run_phase3_robust.py:144-156, and does not).
+        A 1 M-frame dataset is ~1.1 TB; nothing larger than one chunk is ever held on the host."""
+        import json
+        import os
+        os.makedirs(out_dir, exist_ok=True)
+        begin, end = _sharding.shard_range(num_samples, rank, world)
+        manifest = {"split": split, "seed": seed, "rank": rank, "world": world, "begin": begin, "end": end,
+                    "chunk_frames": chunk_frames, "chunks": []}
+        for cid, b0 in enumerate(range(begin, end, chunk_frames)):
+            b1 = min(end, b0 + chunk_frames)
+            path = os.path.join(out_dir, f"{split}_rank{rank:02d}_chunk{cid:04d}.npz")
+            manifest["chunks"].append({"file": os.path.basename(path), "first_frame": b0, "frames": b1 - b0})
+            if os.path.exists(path):
+                continue                                                           # exact resume
+            rec = self._native_range(num_samples, b0, b1, seed, **kwargs)
+            tmp = path + ".tmp.npz"
+            np.savez_compressed(tmp, **rec)
+            os.replace(tmp, path)
+        with open(os.path.join(out_dir, f"{split}_rank{rank:02d}_manifest.json"), "w") as f:
+            json.dump(manifest, f, indent=1)
+        return manifest
+
+    def _native_range(self, num_samples, begin, end, seed, **kwargs):
+        """Frames [begin, end) of a num_samples-frame dataset (helper of the streaming writer)."""
+        # a "world" in which this range is exactly one rank's shard does not exist in general, so generate through the
+        # same code path with an explicit range
+        return self.generate_dataset_native(num_samples, seed=seed, _range=(begin, end), **kwargs)
 
     def save_dataset(self, dataset, filepath: str, format: str = 'npz'):
         """'npz' (np.savez_compressed of the stacked samples) or 'h5' (:129-180).  Accepts the reference's

@@ -62,6 +62,34 @@ def test_native_dataset_schema_and_sharding_invariance(tmp_path):
         gen.save_dataset(whole, str(f), format="bogus")
 
 
+def test_streaming_shard_writer_and_exact_resume(tmp_path):
+    import json
+    import os
+    gen = dg.ChannelEstimationDataset(CFG)
+    N = 50
+    whole = gen.generate_dataset_native(N, seed=7, pattern_group=16)
+    for rank in range(2):
+        man = gen.generate_dataset_native_to_files(N, str(tmp_path), split="train", seed=7, rank=rank, world=2,
+                                                   chunk_frames=11, pattern_group=16)
+        assert sum(c["frames"] for c in man["chunks"]) == 25 and man["begin"] == 25 * rank
+    files = sorted(f for f in os.listdir(tmp_path) if f.endswith(".npz"))
+    assert files[0] == "train_rank00_chunk0000.npz" and len(files) == 6
+    parts = [np.load(tmp_path / f) for f in files]
+    for k in ("rx_symbols", "H_ls", "H_mmse", "frame_index", "snr_db", "channel_type"):
+        assert np.array_equal(np.concatenate([p[k] for p in parts]), whole[k]), k
+    # resume: delete one chunk, rerun -> only that chunk is regenerated, bit-identical
+    victim = tmp_path / "train_rank01_chunk0001.npz"
+    before = np.load(victim)["H_true"].copy()
+    mtimes = {f: os.path.getmtime(tmp_path / f) for f in files}
+    os.remove(victim)
+    gen.generate_dataset_native_to_files(N, str(tmp_path), split="train", seed=7, rank=1, world=2, chunk_frames=11,
+                                         pattern_group=16)
+    assert np.array_equal(np.load(victim)["H_true"], before)
+    assert all(os.path.getmtime(tmp_path / f) == mtimes[f] for f in files if f != victim.name)
+    man = json.load(open(tmp_path / "train_rank01_manifest.json"))
+    assert man["chunks"][1]["first_frame"] == 36 and man["world"] == 2
+
+
 def test_config_sized_batch_properties():
     """BASELINE config 2 at full size (10 000 frames): properties that do not need the oracle."""
     import torch
