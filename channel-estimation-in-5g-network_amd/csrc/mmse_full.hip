@@ -8,6 +8,8 @@
 // apply  : gather h_ls = y/(x+1e-12) for all B*R*T grids, complex GEMM W[P,P] x h_ls[P,M] on the exact-f32
 //          MFMA pipe (v_mfma_f32_32x32x2_f32; 4 real MFMAs per complex k-pair), then the usual plan-driven
 //          interpolation.  This is the only MFMA-shaped work on the hot path.
+#include <stdlib.h>
+
 #include "chest_device.h"
 #include "chest_internal.h"
 
@@ -139,6 +141,76 @@ cgemm_w_kernel(int P, int Ppad, int M, const float2* __restrict__ W, const float
     }
 }
 
+// Second-generation tile: 128 x 128 block, 4 waves x (2 x 2) 32x32 MFMA tiles, i.e. 16 MFMAs per four ds_read_b64 (the
+// 64 x 64 version issues 4 per two).  Rows of the MFMA tile = grids m (registers), columns = pilot index i (lanes), so
+// every C/D register is stored as a 256-B run of Hout[m][i0..i0+31].
+constexpr int T2_M = 128, T2_N = 128, T2_K = 16, T2_LD = T2_K + 1;
+
+__global__ void __launch_bounds__(256)
+cgemm_w_kernel_v2(int P, int Ppad, int M, const float2* __restrict__ W, const float2* __restrict__ Hin,
+                  float2* __restrict__ Hout) {
+    __shared__ float2 Hs[T2_M * T2_LD];        // [m][k]  A operand
+    __shared__ float2 Ws[T2_N * T2_LD];        // [i][k]  B operand
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int i0 = blockIdx.x * T2_N, m0 = blockIdx.y * T2_M;
+    const int wm = (wave & 1) * 64, wi = (wave >> 1) * 64;
+    f32x16 cre[2][2], cim[2][2];
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { cre[x][y][e] = 0.f; cim[x][y][e] = 0.f; }
+    const int lrow = tid >> 1, lk = (tid & 1) * 8;
+    // register-staged software pipeline: the global loads of tile t+1 are issued before the MFMA block of tile t and
+    // written to LDS after it, so their latency hides under ~8k cycles of matrix work per wave
+    float2 ph[8], pw[8];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int k = k0 + lk + q;
+            ph[q] = (m0 + lrow < M && k < Ppad) ? Hin[(size_t)(m0 + lrow) * Ppad + k] : make_float2(0.f, 0.f);
+            pw[q] = (i0 + lrow < P && k < P) ? W[(size_t)(i0 + lrow) * P + k] : make_float2(0.f, 0.f);
+        }
+    };
+    fetch(0);
+    for (int k0 = 0; k0 < Ppad; k0 += T2_K) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { Hs[lrow * T2_LD + lk + q] = ph[q]; Ws[lrow * T2_LD + lk + q] = pw[q]; }
+        __syncthreads();
+        if (k0 + T2_K < Ppad) fetch(k0 + T2_K);
+#pragma unroll
+        for (int kk = 0; kk < T2_K; kk += 2) {
+            float2 a[2], b[2];
+#pragma unroll
+            for (int x = 0; x < 2; ++x) a[x] = Hs[(wm + 32 * x + (lane & 31)) * T2_LD + kk + (lane >> 5)];
+#pragma unroll
+            for (int y = 0; y < 2; ++y) b[y] = Ws[(wi + 32 * y + (lane & 31)) * T2_LD + kk + (lane >> 5)];
+#pragma unroll
+            for (int x = 0; x < 2; ++x)
+#pragma unroll
+                for (int y = 0; y < 2; ++y) {
+                    cre[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[x].x, b[y].x, cre[x][y], 0, 0, 0);
+                    cre[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(-a[x].y, b[y].y, cre[x][y], 0, 0, 0);
+                    cim[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[x].x, b[y].y, cim[x][y], 0, 0, 0);
+                    cim[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[x].y, b[y].x, cim[x][y], 0, 0, 0);
+                }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y) {
+            const int i = i0 + wi + 32 * y + (lane & 31);
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int m = m0 + wm + 32 * x + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+                if (m < M && i < P) Hout[(size_t)m * Ppad + i] = make_float2(cre[x][y][reg], cim[x][y][reg]);
+            }
+        }
+}
+
 // plan-driven interpolation of precomputed pilot values h[m][Ppad] (same arithmetic as estimate_kernel)
 __global__ void __launch_bounds__(256)
 interp_from_pilots_kernel(int S, int R, int T, int nsc, int Ppad, const PatternDev* __restrict__ patterns, int slot,
@@ -262,8 +334,12 @@ int chest_mmse_full_apply(chest_ctx* ctx, void* stream, int32_t B, const float* 
     float2* h_out = h_in + (size_t)M * Ppad;
     hipLaunchKernelGGL(gather_ls_kernel, dim3(M), dim3(256), 0, st, f.S, f.R, f.T, f.nsc, P, Ppad, pd.pilot_idx,
                        (const float2*)rx4d, (const float2*)tx_pilots, pilot_stride, h_in);
-    hipLaunchKernelGGL(cgemm_w_kernel, dim3((P + GB_M - 1) / GB_M, (M + GB_N - 1) / GB_N), dim3(256), 0, st, P, Ppad, M,
-                       (const float2*)W, h_in, h_out);
+    if (getenv("CHEST_GEMM_V1"))          // A/B switch for the first-generation 64x64 tile
+        hipLaunchKernelGGL(cgemm_w_kernel, dim3((P + GB_M - 1) / GB_M, (M + GB_N - 1) / GB_N), dim3(256), 0, st, P, Ppad, M,
+                           (const float2*)W, h_in, h_out);
+    else
+        hipLaunchKernelGGL(cgemm_w_kernel_v2, dim3((P + T2_N - 1) / T2_N, (M + T2_M - 1) / T2_M), dim3(256), 0, st, P, Ppad, M,
+                           (const float2*)W, h_in, h_out);
     const size_t lds = (size_t)P * sizeof(float2);
     if (lds > 64 * 1024)
         CHEST_HIP(hipFuncSetAttribute((const void*)interp_from_pilots_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
