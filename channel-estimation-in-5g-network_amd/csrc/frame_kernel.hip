@@ -20,6 +20,8 @@
 //                      interleave at 1 KiB -- tools/micro/store_wave_runs.hip).  Tap gains come in through SCALAR
 //                      loads (SGPR operands of the FMAs), tap twiddles from an LDS table built once per frame;
 //                      everything else lives in registers and the kernel only WRITES to HBM, 16 B per lane.
+#include <stdlib.h>
+
 #include "chest_device.h"
 #include "chest_internal.h"
 
@@ -415,10 +417,17 @@ __global__ void __launch_bounds__(CHEST_K2_BOUNDS, CHEST_K2_MINWAVES)
 frame_kernel(const FrameParams* __restrict__ fpp, const chest_frame_desc* __restrict__ descs,
              const PatternDev* __restrict__ patterns, int Pmax, uint64_t seed, uint64_t frame_offset,
              const chest_injected inj, const chest_frame_outputs out, const float* __restrict__ state,
-             int nch, int* __restrict__ status) {
+             int nch, int xcd_remap, int* __restrict__ status) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const FrameParams& fp = *fpp;
-    const int b = blockIdx.x, tid = threadIdx.x;
+    const int tid = threadIdx.x;
+    int b = blockIdx.x;
+    if (xcd_remap) {
+        // Workgroups are dealt round-robin over the 8 XCDs (b % 8 labels the blocks that share one).  Give each XCD a
+        // contiguous frame range: its L2 then holds one pattern group's tables and its writes are one sequential region.
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, x = b & 7;
+        b = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);      // bijective for any grid size
+    }
     const int S = fp.S, T = fp.T, R = fp.R, nsc = fp.nsc, G = fp.G;
     const float* rec = state + (size_t)b * frame_state_floats(S, R, T);
     const chest_frame_desc fd = descs[b];
@@ -490,7 +499,7 @@ static int launch_k2(chest_ctx* ctx, hipStream_t st, int32_t B, int nch, const c
         attr = lds2;
     }
     hipLaunchKernelGGL(frame_kernel, dim3(B), dim3(ctx->block_threads), lds2, st, ctx->d_fp, descs, ctx->d_patterns,
-                       Pmax, seed, frame_offset, inj, out, workspace, nch, ctx->d_status);
+                       Pmax, seed, frame_offset, inj, out, workspace, nch, getenv("CHEST_NO_XCD_REMAP") ? 0 : 1, ctx->d_status);
     return CHEST_OK;
 }
 
