@@ -168,6 +168,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    eng.profile_begin(args.steps)            # library-side HIP events around each kernel, on the launch stream
     t0 = time.perf_counter()
     for i in range(args.steps):
         ev[i][0].record()
@@ -190,7 +191,9 @@ def main():
         tmax = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
-    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    call_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))      # one chest_frames_run call = taps + frame kernels
+    taps_ms, kern_ms, _ = eng.profile_read()                             # each kernel on its own
+    eng.profile_begin(0)
 
     if rank == 0:
         bytes_frame = algorithmic_bytes_per_frame(S, nsc, T, R, P, 2)
@@ -215,7 +218,8 @@ def main():
                        "rng": "Philox4x32-10 on device", "outputs": names, "parallelism": f"frames sharded x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "frame_kernel",
-                         "kernel_ms": kern_ms, "bytes_per_frame": bytes_frame},
+                         "kernel_ms": kern_ms, "taps_kernel_ms": taps_ms, "call_ms": call_ms,
+                         "bytes_per_frame": bytes_frame},
         }
         if s[3] > 0:
             res["est_mse"] = {"ls": float(s[1] / s[3]), "mmse": float(s[2] / s[3]),

@@ -55,6 +55,8 @@ SIGNATURES = {
     "chest_pattern_set": (_i32, [_vp, _i32, _vp, _i32, _vp, _vp]),
     "chest_pattern_num_pilots": (_i32, [_vp, _i32]),
     "chest_get_status": (_i32, [_vp, C.POINTER(_i32)]),
+    "chest_profile_begin": (_i32, [_vp, _i32]),
+    "chest_profile_read": (_i32, [_vp, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(_i32)]),
     "chest_frames_workspace_bytes": (_i64, [_vp, _i32]),
     "chest_frames_run": (_i32, [_vp, _vp, _i32, _vp, _u64, _u64, C.POINTER(Injected), C.POINTER(FrameOutputs), _vp, _i64]),
     "chest_estimate_batch": (_i32, [_vp, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _f, _vp]),

@@ -192,6 +192,7 @@ void chest_destroy(chest_ctx* ctx) {
     if (ctx->d_twiddle) (void)hipFree(ctx->d_twiddle);
     if (ctx->d_gram) (void)hipFree(ctx->d_gram);
     if (ctx->d_fp) (void)hipFree(ctx->d_fp);
+    for (void* e : ctx->prof_events) (void)hipEventDestroy((hipEvent_t)e);
     delete ctx;
 }
 
@@ -305,6 +306,38 @@ int chest_get_status(chest_ctx* ctx, int32_t* status) {
 int64_t chest_frames_workspace_bytes(chest_ctx* ctx, int32_t num_frames) {
     if (!ctx || num_frames < 0) return 0;
     return (int64_t)frames_workspace_bytes(ctx, num_frames);
+}
+
+int chest_profile_begin(chest_ctx* ctx, int32_t capacity) {
+    if (!ctx || capacity < 0) { set_error("chest_profile_begin: bad argument"); return CHEST_EINVAL; }
+    CHEST_HIP(hipSetDevice(ctx->cfg.device));
+    for (void* e : ctx->prof_events) (void)hipEventDestroy((hipEvent_t)e);
+    ctx->prof_events.clear();
+    ctx->prof_used = 0;
+    for (int i = 0; i < capacity * 3; ++i) {
+        hipEvent_t ev = nullptr;
+        CHEST_HIP(hipEventCreate(&ev));
+        ctx->prof_events.push_back(ev);
+    }
+    return CHEST_OK;
+}
+
+int chest_profile_read(chest_ctx* ctx, float* taps_ms, float* frame_ms, int32_t* count) {
+    if (!ctx || !taps_ms || !frame_ms || !count) { set_error("chest_profile_read: null argument"); return CHEST_EINVAL; }
+    double t = 0.0, f = 0.0;
+    for (int i = 0; i < ctx->prof_used; ++i) {
+        hipEvent_t* e = (hipEvent_t*)&ctx->prof_events[(size_t)i * 3];
+        CHEST_HIP(hipEventSynchronize(e[2]));
+        float a = 0.f, b = 0.f;
+        CHEST_HIP(hipEventElapsedTime(&a, e[0], e[1]));
+        CHEST_HIP(hipEventElapsedTime(&b, e[1], e[2]));
+        t += a; f += b;
+    }
+    *count = ctx->prof_used;
+    *taps_ms = ctx->prof_used ? (float)(t / ctx->prof_used) : 0.f;
+    *frame_ms = ctx->prof_used ? (float)(f / ctx->prof_used) : 0.f;
+    ctx->prof_used = 0;
+    return CHEST_OK;
 }
 
 int chest_frames_run(chest_ctx* ctx, void* stream, int32_t B, const chest_frame_desc* descs, uint64_t seed,

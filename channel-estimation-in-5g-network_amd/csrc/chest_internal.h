@@ -67,6 +67,8 @@ struct chest_ctx {
     float2* d_twiddle = nullptr;   // FFT twiddles exp(-2 pi j n/N), n < N (power-of-two N only)
     float2* d_gram = nullptr;      // [3][KT][KT] Gram matrices of the tap twiddles over the used bins
     chest::FrameParams* d_fp = nullptr;   // device copy of fp (kernels read it through uniform scalar loads)
+    std::vector<void*> prof_events;       // hipEvent_t triples (before taps, before frame kernel, after) when profiling
+    int32_t prof_used = 0;                // triples recorded since chest_profile_begin
 };
 
 namespace chest {

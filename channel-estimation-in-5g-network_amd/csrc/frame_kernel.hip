@@ -532,10 +532,16 @@ int launch_frames(chest_ctx* ctx, hipStream_t st, int32_t B, const chest_frame_d
         return CHEST_EINVAL;
     }
     const int nch = (fp.nsc + 125) / 126;
+    // optional per-kernel timing (chest_profile_begin): events on the launch stream around each of the two kernels
+    hipEvent_t* pev = nullptr;
+    if ((size_t)(ctx->prof_used + 1) * 3 <= ctx->prof_events.size()) pev = (hipEvent_t*)&ctx->prof_events[(size_t)ctx->prof_used * 3];
+    if (pev) CHEST_HIP(hipEventRecord(pev[0], st));
     hipLaunchKernelGGL(taps_kernel, dim3(B), dim3(256), lds1, st, ctx->d_fp, descs, (int)ctx->patterns.size(), ctx->d_gram, seed,
                        frame_offset, inj_v.u_angle, inj_v.u_phase, inj_v.inj_paths, (float*)workspace, ctx->d_status);
+    if (pev) CHEST_HIP(hipEventRecord(pev[1], st));
     const int rc = launch_k2(ctx, st, B, nch, descs, Pmax, seed, frame_offset, inj_v, *out, (const float*)workspace);
     if (rc != CHEST_OK) return rc;
+    if (pev) { CHEST_HIP(hipEventRecord(pev[2], st)); ++ctx->prof_used; }
     CHEST_HIP(hipGetLastError());
     return CHEST_OK;
 }

@@ -171,6 +171,16 @@ class Engine:
         if st.value == 2:
             raise N.ChestError("estimates were requested for a pattern that has no interpolation plan")
 
+    def profile_begin(self, capacity: int):
+        """Record HIP events around the taps and frame kernels of the next `capacity` run_frames calls."""
+        N.check(N.lib().chest_profile_begin(self._h, int(capacity)), "chest_profile_begin")
+
+    def profile_read(self):
+        """(taps_kernel ms, frame_kernel ms, calls averaged); synchronises."""
+        a, b, n = C.c_float(), C.c_float(), C.c_int32()
+        N.check(N.lib().chest_profile_read(self._h, C.byref(a), C.byref(b), C.byref(n)), "chest_profile_read")
+        return a.value, b.value, n.value
+
     # ---- helpers ----------------------------------------------------------------------------------
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)

@@ -133,6 +133,13 @@ int chest_pattern_num_pilots(chest_ctx* ctx, int32_t slot);
  * plan (2); reading it synchronises the device and clears it. HOST out. */
 int chest_get_status(chest_ctx* ctx, int32_t* status);
 
+/* Per-kernel timing of chest_frames_run (measurement aid): after chest_profile_begin(ctx, n) the next n calls record
+ * HIP events on their launch stream before the taps kernel, before the frame kernel and after it;
+ * chest_profile_read synchronises on them, returns the average duration of each kernel in milliseconds and the number
+ * of calls averaged, and re-arms.  chest_profile_begin(ctx, 0) turns it off.  Do not use while capturing a graph. */
+int chest_profile_begin(chest_ctx* ctx, int32_t capacity);
+int chest_profile_read(chest_ctx* ctx, float* taps_ms, float* frame_ms, int32_t* count);
+
 /* ---- launch group (asynchronous, no allocation) -------------------------------------------- */
 
 /* Fused frame pipeline: simulate_transmission (:348-421) -> LSEstimator.estimate
