@@ -163,16 +163,32 @@ class ChannelEstimationDataset:
         begin, end = _sharding.shard_range(num_samples, rank, world)
         manifest = {"split": split, "seed": seed, "rank": rank, "world": world, "begin": begin, "end": end,
                     "chunk_frames": chunk_frames, "chunks": []}
+        records = []
         for cid, b0 in enumerate(range(begin, end, chunk_frames)):
             b1 = min(end, b0 + chunk_frames)
             path = os.path.join(out_dir, f"{split}_rank{rank:02d}_chunk{cid:04d}.npz")
             manifest["chunks"].append({"file": os.path.basename(path), "first_frame": b0, "frames": b1 - b0})
-            if os.path.exists(path):
-                continue                                                           # exact resume
-            rec = self._native_range(num_samples, b0, b1, seed, **kwargs)
-            tmp = path + ".tmp.npz"
-            np.savez_compressed(tmp, **rec)
-            os.replace(tmp, path)
+            if os.path.exists(path):                                               # exact resume
+                with np.load(path) as z:
+                    rec = {k: z[k] for k in ("frame_index", "snr_db", "doppler_hz", "pilot_density", "channel_type", "metrics")}
+            else:
+                rec = self._native_range(num_samples, b0, b1, seed, **kwargs)
+                tmp = path + ".tmp.npz"
+                np.savez_compressed(tmp, **rec)
+                os.replace(tmp, path)
+            ct = np.asarray([CHANNEL_NAMES.index(str(c)) for c in rec["channel_type"]], dtype=np.float32)
+            m = np.asarray(rec["metrics"], dtype=np.float32)
+            records.append(np.column_stack([np.asarray(rec["frame_index"], dtype=np.float32), ct, rec["doppler_hz"], rec["snr_db"],
+                                            rec["pilot_density"], m[:, 0], m[:, 1], m[:, 2], m[:, 6]]).astype(np.float32))
+        # the job's single collective: every rank's per-frame (index, type, doppler, snr, density, sum|H|^2, LS / MMSE error
+        # sums, count) records, 36 B per frame (the tensors stay in their rank's shard files)
+        local = np.concatenate(records) if records else np.zeros((0, 9), np.float32)
+        allrec = _sharding.gather_records(local)
+        tot = allrec[:, 8].sum() if len(allrec) else 1.0
+        manifest["summary"] = {"frames_all_ranks": int(len(allrec)),
+                               "mse_ls": float(allrec[:, 6].sum() / tot) if len(allrec) else None,
+                               "mse_mmse": float(allrec[:, 7].sum() / tot) if len(allrec) else None,
+                               "frames_per_channel_type": {n: int((allrec[:, 1] == i).sum()) for i, n in enumerate(CHANNEL_NAMES)}}
         with open(os.path.join(out_dir, f"{split}_rank{rank:02d}_manifest.json"), "w") as f:
             json.dump(manifest, f, indent=1)
         return manifest

@@ -88,6 +88,11 @@ def test_streaming_shard_writer_and_exact_resume(tmp_path):
     assert all(os.path.getmtime(tmp_path / f) == mtimes[f] for f in files if f != victim.name)
     man = json.load(open(tmp_path / "train_rank01_manifest.json"))
     assert man["chunks"][1]["first_frame"] == 36 and man["world"] == 2
+    # no process group here: the "gather" is this rank's own 25 records; the summary matches the stored tensors
+    assert man["summary"]["frames_all_ranks"] == 25 and sum(man["summary"]["frames_per_channel_type"].values()) == 25
+    sel = whole["frame_index"] >= 25
+    err = np.abs(whole["H_true"][sel] - whole["H_ls"][sel]) ** 2
+    assert man["summary"]["mse_ls"] == pytest.approx(float(err.mean()), rel=1e-4)
 
 
 def test_config_sized_batch_properties():

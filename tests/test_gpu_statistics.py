@@ -102,3 +102,30 @@ def test_launch_group_is_hip_graph_capturable():
     for k in names:
         assert torch.equal(out[k], eager[k]), k
     eng.check_status()
+
+
+def test_snr_sweep_matches_reference_curve():
+    """BASELINE config 3's shape (ETU 370.4 Hz, SNR -5..30 dB, LS + MMSE), reduced to 2x2: frame-averaged MSE of both
+    estimators per SNR against the curve the REAL reference produced (tools/make_snr_sweep_golden.py, 30 frames per SNR).
+    Different random streams, so the comparison is statistical: 4 standard errors of the reference mean + 2 %."""
+    import json
+    import os
+    from conftest import GOLDEN
+    ref = json.load(open(os.path.join(GOLDEN, "snr_sweep_ref.json")))
+    geom = E.Geometry()
+    eng = E.get_engine(geom, 0)
+    G = geom.grid
+    slots = [eng.pattern_slot(np.sort(np.random.RandomState(900 + g).permutation(G)[:838]), "linear") for g in range(20)]
+    F = 2000
+    for row in ref["snr"]:
+        d = E.make_descs("ETU", ref["doppler_hz"], float(row["snr_db"]), np.asarray(slots, np.int32)[np.arange(F) // 100], n=F)
+        m = eng.run_frames(d, seed=31337, frame_offset=int(row["snr_db"] + 100) * 10**6, outputs=("metrics",))["metrics"].double()
+        mse_ls = float((m[:, 1] / m[:, 6]).mean())
+        mse_mm = float((m[:, 2] / m[:, 6]).mean())
+        power = float((m[:, 0] / m[:, 6]).mean())
+        n = ref["frames_per_snr"] ** 0.5
+        assert abs(mse_ls - row["mse_ls"]) < 4 * row["mse_ls_std"] / n + 0.02 * row["mse_ls"], (row["snr_db"], mse_ls, row["mse_ls"])
+        assert abs(mse_mm - row["mse_mmse"]) < 4 * row["mse_mmse_std"] / n + 0.02 * row["mse_mmse"], (row["snr_db"], mse_mm, row["mse_mmse"])
+        assert power == pytest.approx(0.5, rel=0.02)               # E|H|^2 of ETU (all nine paths survive) = 0.5
+        assert power == pytest.approx(row["power"], rel=0.15)        # the reference's 30-frame mean fluctuates by ~4 % rms
+        assert mse_mm <= mse_ls
