@@ -21,6 +21,7 @@ import numpy as np
 
 from . import channel_simulator as _cs
 from . import engine as _engine
+from . import interp_plan as _interp_plan
 from . import sharding as _sharding
 
 CHANNEL_NAMES = ("EPA", "EVA", "ETU")
@@ -94,7 +95,7 @@ class ChannelEstimationDataset:
     def generate_dataset_native(self, num_samples: int, seed: int = 42, rank: int = 0, world: int = 1,
                                 batch_frames: int = 4096, pattern_group: int = 1024, with_mmse: bool = True,
                                 channel_types=None, doppler_values=None, snr_values=None, pilot_densities=None,
-                                to_numpy: bool = True, _range=None) -> Dict:
+                                to_numpy: bool = True, plan_workers: int = 0, _range=None) -> Dict:
         """Frames [begin, end) of this rank out of ``num_samples``, on the device RNG.
 
         Per-frame parameters are counter-based choices (``sharding.frame_choices``) from the same value
@@ -122,13 +123,19 @@ class ChannelEstimationDataset:
         dens = np.asarray(pilot_densities, dtype=np.float64)[pi]
         group = idx // pattern_group
         slots = np.empty(n, dtype=np.int32)
-        for key in sorted(set(zip(pi.tolist(), group.tolist()))):
+        keys = sorted(set(zip(pi.tolist(), group.tolist())))
+        pils = []
+        for key in keys:
             d = float(pilot_densities[key[0]])
             rs = np.random.RandomState((int(seed) * 1000003 + key[1] * 101 + key[0]) % (2**32))
             perm = np.arange(G)
             rs.shuffle(perm)                                                         # PilotPattern's algorithm (:227-229)
-            pil = np.sort(perm[: int(G * d)])
-            slots[(pi == key[0]) & (group == key[1])] = eng.pattern_slot(pil, "linear")
+            pils.append(np.sort(perm[: int(G * d)]))
+        # interpolation plans (Qhull + point location, ~10 ms per pattern per core) optionally in a process pool
+        plans = _interp_plan.build_plans_parallel(pils, S, nsc, "linear", plan_workers) if plan_workers > 1 else [None] * len(pils)
+        eng.max_cached_patterns = max(eng.max_cached_patterns, len(keys) + 8)
+        for key, pil, plan in zip(keys, pils, plans):
+            slots[(pi == key[0]) & (group == key[1])] = eng.pattern_slot(pil, "linear", plan=plan)
         names = ["tx", "rx", "H", "H_ls", "pilot_mask", "metrics"] + (["H_mmse"] if with_mmse else [])
         chunks = {k: [] for k in names}
         for b0 in range(0, n, batch_frames):

@@ -137,17 +137,17 @@ class Engine:
         self._next_slot = max(self._next_slot, int(slot) + 1)
         return int(slot)
 
-    def pattern_slot(self, pilot_idx, method="linear", with_plan=True):
+    def pattern_slot(self, pilot_idx, method="linear", with_plan=True, plan=None):
         """Slot for a pattern, uploading it (and building its plan) on first use.  At most
         ``max_cached_patterns`` auto-managed patterns stay resident; the least recently used slot is
-        re-used after that (single-frame drop-in calls draw a new random pattern every frame)."""
+        re-used after that (single-frame drop-in calls draw a new random pattern every frame).  ``plan`` may carry a
+        plan built elsewhere (interp_plan.build_plans_parallel)."""
         key = interp_plan.pattern_key(pilot_idx, method if with_plan else None)
         slot = self._slots.get(key)
         if slot is not None:
             self._slots[key] = self._slots.pop(key)           # mark most recently used
             return slot
-        plan = None
-        if with_plan:
+        if with_plan and plan is None:
             S, nsc = self.geom.num_symbols, self.geom.num_sc
             ps, pk = np.unravel_index(np.asarray(pilot_idx, dtype=np.int64), (S, nsc))
             plan = interp_plan.build_plan(ps, pk, S, nsc, method)

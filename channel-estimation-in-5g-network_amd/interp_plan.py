@@ -105,6 +105,26 @@ def build_plan(pilot_sym, pilot_sc, S, nsc, method="linear"):
     return hit
 
 
+def _plan_job(args):
+    """Worker entry point of build_plans_parallel (top-level so that it pickles)."""
+    pilot_idx, S, nsc, method = args
+    ps, pk = np.unravel_index(np.asarray(pilot_idx, dtype=np.int64), (S, nsc))
+    return linear_plan(ps, pk, S, nsc) if method == "linear" else nearest_plan(ps, pk, S, nsc)
+
+
+def build_plans_parallel(pilot_idx_list, S, nsc, method="linear", workers=0):
+    """Plans for many patterns; with workers > 1 in a spawn-context process pool (Qhull + point location cost ~10 ms per
+    full-size pattern per core and hold the GIL).  Results are in input order and identical to build_plan's."""
+    if method not in ("linear", "nearest"):
+        raise ValueError(f"Unknown interpolation method: {method}")
+    jobs = [(np.asarray(p, dtype=np.int64), S, nsc, method) for p in pilot_idx_list]
+    if workers and workers > 1 and len(jobs) > 1:
+        import multiprocessing as mp
+        with mp.get_context("spawn").Pool(min(workers, len(jobs))) as pool:
+            return pool.map(_plan_job, jobs, chunksize=max(1, len(jobs) // (4 * workers)))
+    return [_plan_job(j) for j in jobs]
+
+
 def pattern_key(pilot_idx, method):
     a = np.ascontiguousarray(pilot_idx, dtype=np.int64)
     return (method, hashlib.blake2b(a.tobytes(), digest_size=16).digest())

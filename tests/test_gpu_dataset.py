@@ -39,6 +39,12 @@ def test_native_dataset_schema_and_sharding_invariance(tmp_path):
     parts = [gen.generate_dataset_native(N, seed=42, rank=r, world=3, pattern_group=32, batch_frames=17) for r in range(3)]
     for k in ("rx_symbols", "H_true", "H_ls", "H_mmse", "pilot_mask", "snr_db", "doppler_hz", "frame_index", "metrics"):
         assert np.array_equal(np.concatenate([p[k] for p in parts]), whole[k]), k
+    # small pattern groups with the plans built in a worker pool: identical frames
+    a = gen.generate_dataset_native(24, seed=5, pattern_group=3)
+    b = gen.generate_dataset_native(24, seed=5, pattern_group=3, plan_workers=4)
+    for k in ("H_ls", "H_mmse", "pilot_mask"):
+        assert np.array_equal(a[k], b[k])
+    assert len({m.tobytes() for m in a["pilot_mask"]}) >= 8          # 8 groups x 2 densities -> many distinct patterns
     # spot-check one frame against the float64 oracle on the same Philox streams
     i = 37
     mask = whole["pilot_mask"][i].astype(bool)

@@ -154,3 +154,15 @@ def test_cubic_operator_reproduces_griddata_cubic():
     assert np.max(np.abs(got[ps, pk] - h_p)) < 1e-5 * np.max(np.abs(h_p))        # exact at the pilots
     with pytest.raises(ValueError):
         ip.build_plan(ps, pk, S, nsc, "cubic")                                   # cubic has no 3-point plan
+
+
+def test_parallel_plan_builder_equals_serial():
+    rs = np.random.RandomState(2)
+    pils = [np.sort(rs.permutation(14 * 71)[:60 + 7 * i]) for i in range(6)]
+    serial = ip.build_plans_parallel(pils, 14, 71, "linear", workers=0)
+    pooled = ip.build_plans_parallel(pils, 14, 71, "linear", workers=3)
+    for (i0, w0), (i1, w1), p in zip(serial, pooled, pils):
+        assert np.array_equal(i0, i1) and np.array_equal(w0, w1)
+        ps, pk = np.unravel_index(p, (14, 71))
+        ref = ip.build_plan(ps, pk, 14, 71, "linear")
+        assert np.array_equal(i0, ref[0]) and np.array_equal(w0, ref[1])
