@@ -61,11 +61,7 @@ int launch_estimate(chest_ctx* ctx, hipStream_t st, int32_t B, const float* rx4d
     if (pd.plan == nullptr) { set_error("pattern slot %d has no interpolation plan", slot); return CHEST_ESTATE; }
     const size_t lds = (size_t)pd.P * sizeof(float2) + 32 * sizeof(float);
     if (lds > 160 * 1024) { set_error("too many pilots for LDS"); return CHEST_EINVAL; }
-    static thread_local size_t lds_attr = 0;
-    if (lds > 64 * 1024 && lds > lds_attr) {
-        CHEST_HIP(hipFuncSetAttribute((const void*)estimate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        lds_attr = lds;
-    }
+    CHEST_LDS_OPT_IN(ctx, LDS_ESTIMATE, estimate_kernel, lds);
     const auto& f = ctx->fp;
     hipLaunchKernelGGL(estimate_kernel, dim3((unsigned)(B * f.R * f.T)), dim3(256), lds, st, f.S, f.R, f.T, f.nsc,
                        ctx->d_patterns, slot, (const float2*)rx4d, (const float2*)tx_pilots, pilot_stride, mmse,

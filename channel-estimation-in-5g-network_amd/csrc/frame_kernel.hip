@@ -493,11 +493,7 @@ static int launch_k2(chest_ctx* ctx, hipStream_t st, int32_t B, int nch, const c
                      const float* workspace) {
     const size_t lds2 = k2_lds_bytes(nch, Pmax, ctx->fp.R);
     if (lds2 > 160 * 1024) { set_error("frame kernel needs %zu B of LDS (> 160 KiB): too many antennas or pilots", lds2); return CHEST_EINVAL; }
-    static thread_local size_t attr = 0;
-    if (lds2 > 64 * 1024 && lds2 > attr) {
-        CHEST_HIP(hipFuncSetAttribute((const void*)frame_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
-        attr = lds2;
-    }
+    CHEST_LDS_OPT_IN(ctx, LDS_FRAME, frame_kernel, lds2);
     hipLaunchKernelGGL(frame_kernel, dim3(B), dim3(ctx->block_threads), lds2, st, ctx->d_fp, descs, ctx->d_patterns,
                        Pmax, seed, frame_offset, inj, out, workspace, nch, getenv("CHEST_NO_XCD_REMAP") ? 0 : 1, ctx->d_status);
     return CHEST_OK;
@@ -520,11 +516,7 @@ int launch_frames(chest_ctx* ctx, hipStream_t st, int32_t B, const chest_frame_d
     for (const auto& p : ctx->patterns) Pmax = p.dev.P > Pmax ? p.dev.P : Pmax;
     const size_t lds1 = ((size_t)KT * fp.T * fp.R * CHEST_NUM_OSC + (size_t)fp.S * fp.R * KTS) * sizeof(float2) + 32 * sizeof(float);
     if (lds1 > 160 * 1024) { set_error("taps kernel needs %zu B of LDS (> 160 KiB): too many antennas", lds1); return CHEST_EINVAL; }
-    static thread_local size_t attr1 = 0;
-    if (lds1 > 64 * 1024 && lds1 > attr1) {
-        CHEST_HIP(hipFuncSetAttribute((const void*)taps_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
-        attr1 = lds1;
-    }
+    CHEST_LDS_OPT_IN(ctx, LDS_TAPS, taps_kernel, lds1);
     chest_injected inj_v{};
     if (inj != nullptr) inj_v = *inj;
     if ((inj_v.u_angle == nullptr) != (inj_v.u_phase == nullptr) || (inj_v.n_re == nullptr) != (inj_v.n_im == nullptr)) {

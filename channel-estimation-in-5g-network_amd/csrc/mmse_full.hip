@@ -341,8 +341,7 @@ int chest_mmse_full_apply(chest_ctx* ctx, void* stream, int32_t B, const float* 
         hipLaunchKernelGGL(cgemm_w_kernel_v2, dim3((P + T2_N - 1) / T2_N, (M + T2_M - 1) / T2_M), dim3(256), 0, st, P, Ppad, M,
                            (const float2*)W, h_in, h_out);
     const size_t lds = (size_t)P * sizeof(float2);
-    if (lds > 64 * 1024)
-        CHEST_HIP(hipFuncSetAttribute((const void*)interp_from_pilots_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    CHEST_LDS_OPT_IN(ctx, LDS_INTERP, interp_from_pilots_kernel, lds);
     hipLaunchKernelGGL(interp_from_pilots_kernel, dim3(M), dim3(256), lds, st, f.S, f.R, f.T, f.nsc, Ppad, ctx->d_patterns,
                        slot, h_out, (float2*)H_est);
     CHEST_HIP(hipGetLastError());
