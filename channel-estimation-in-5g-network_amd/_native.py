@@ -69,6 +69,10 @@ SIGNATURES = {
     "chest_equalize": (_i32, [_vp, _vp, _i32, _vp, _vp, _i32, _vp]),
     "chest_tdl_apply": (_i32, [_vp, _vp, _i32, _i64, _i32, _i32, _vp, _vp, _vp]),
     "chest_pack_ml_inputs": (_i32, [_vp, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp]),
+    "chest_qam_constellation": (_i32, [_i32, _vp, _vp]),
+    "chest_qam_modulate": (_i32, [_vp, _vp, _i32, _i64, _vp, _i32, _vp]),
+    "chest_qam_demodulate": (_i32, [_vp, _vp, _i32, _i64, _i32, _vp, _vp]),
+    "chest_bit_errors": (_i32, [_vp, _vp, _i64, _vp, _vp, _vp]),
     "chest_mmse_full_prepare": (_i32, [_vp, _vp, _i32, _vp, _f, _vp, _vp, _i64]),
     "chest_mmse_full_workspace_bytes": (_i64, [_i32]),
     "chest_estimate_dense": (_i32, [_vp, _vp, _i32, _vp, _vp, _i32, _i32, _vp, _vp, _vp]),

@@ -414,4 +414,27 @@ int chest_pack_ml_inputs(chest_ctx* ctx, void* stream, int32_t B, const float* r
     return launch_pack_ml(ctx, (hipStream_t)stream, B, rx, H_ls, H_true, mask, normalize, inputs, targets);
 }
 
+int chest_qam_constellation(int32_t M, double* points, int32_t* gray_map) { return qam_constellation_host(M, points, gray_map); }
+
+int chest_qam_modulate(chest_ctx* ctx, void* stream, int32_t M, int64_t n, const uint8_t* bits, int32_t wide, void* symbols) {
+    if (!ctx || n < 0 || (n > 0 && (!bits || !symbols)) || ((uintptr_t)bits & 3)) {
+        set_error("chest_qam_modulate: bad argument (bits must be 4-byte aligned)");
+        return CHEST_EINVAL;
+    }
+    return launch_qam_mod(ctx, (hipStream_t)stream, M, n, bits, wide, symbols);
+}
+
+int chest_qam_demodulate(chest_ctx* ctx, void* stream, int32_t M, int64_t n, int32_t wide, const void* symbols, uint8_t* bits) {
+    if (!ctx || n < 0 || (n > 0 && (!bits || !symbols)) || ((uintptr_t)bits & 3)) {
+        set_error("chest_qam_demodulate: bad argument (bits must be 4-byte aligned)");
+        return CHEST_EINVAL;
+    }
+    return launch_qam_demod(ctx, (hipStream_t)stream, M, n, wide, symbols, bits);
+}
+
+int chest_bit_errors(chest_ctx* ctx, void* stream, int64_t n, const uint8_t* a, const uint8_t* b, uint64_t* count) {
+    if (!ctx || n < 0 || !count || (n > 0 && (!a || !b))) { set_error("chest_bit_errors: bad argument"); return CHEST_EINVAL; }
+    return launch_bit_errors(ctx, (hipStream_t)stream, n, a, b, count);
+}
+
 }  // extern "C"

@@ -116,4 +116,10 @@ int launch_tdl(chest_ctx* ctx, hipStream_t st, int32_t type, int64_t ns, int32_t
                float* y);
 int launch_pack_ml(chest_ctx* ctx, hipStream_t st, int32_t B, const float* rx, const float* Hls, const float* Htrue,
                    const uint8_t* mask, int32_t normalize, float* inputs, float* targets);
+struct QamTable;
+int qam_table(int32_t M, QamTable* t);
+int launch_qam_mod(chest_ctx* ctx, hipStream_t st, int32_t M, int64_t n, const uint8_t* bits, int32_t wide, void* out);
+int launch_qam_demod(chest_ctx* ctx, hipStream_t st, int32_t M, int64_t n, int32_t wide, const void* sym, uint8_t* bits);
+int launch_bit_errors(chest_ctx* ctx, hipStream_t st, int64_t n, const uint8_t* a, const uint8_t* b, uint64_t* count);
+int qam_constellation_host(int32_t M, double* points, int32_t* gray_map);
 }  // namespace chest

@@ -489,6 +489,47 @@ class Engine:
                                        0 if method == "zf" else 1, out.data_ptr()), "chest_equalize")
         return out
 
+    # ---- QPSK / 16-QAM / BER helpers (src/utils.py:71-158) -----------------------------------------------
+    def qam_modulate(self, bits, M=4, wide=False):
+        """bits (0/1, one element per bit, MSB of a symbol first) -> constellation points; trailing bits that do
+        not fill a symbol are dropped (:84-87).  Device tensor complex64 (or complex128 with ``wide``)."""
+        bps = {4: 2, 16: 4}.get(int(M))
+        if bps is None:
+            raise NotImplementedError(f"Modulation order {M} not implemented")
+        b = self._dev(bits, torch.uint8).reshape(-1)
+        n = b.numel() // bps
+        out = torch.empty(n, dtype=torch.complex128 if wide else torch.complex64, device=self.device)
+        N.check(N.lib().chest_qam_modulate(self._h, self._stream(), int(M), n, b.data_ptr(), int(bool(wide)), out.data_ptr()),
+                "chest_qam_modulate")
+        return out
+
+    def qam_demodulate(self, symbols, M=4):
+        """Minimum-distance decisions -> uint8 device tensor of bits, MSB first, flattened (:139-153).  complex128
+        input is decided in float64 as given; anything else is taken as complex64."""
+        bps = {4: 2, 16: 4}.get(int(M))
+        if bps is None:
+            raise NotImplementedError(f"Demodulation order {M} not implemented")
+        wide = (symbols.dtype == torch.complex128) if isinstance(symbols, torch.Tensor) else \
+            (np.asarray(symbols).dtype == np.complex128)
+        s = self._dev(symbols, torch.complex128 if wide else torch.complex64)
+        if s.dim() != 1:
+            raise ValueError("symbols must be one-dimensional")
+        bits = torch.empty(s.numel() * bps, dtype=torch.uint8, device=self.device)
+        N.check(N.lib().chest_qam_demodulate(self._h, self._stream(), int(M), s.numel(), int(wide), s.data_ptr(),
+                                             bits.data_ptr()), "chest_qam_demodulate")
+        return bits
+
+    def bit_errors(self, a, b):
+        """Number of differing positions of two equally long bit strings (device uint64 scalar as int64 tensor)."""
+        x, y = self._dev(a, torch.uint8).reshape(-1), self._dev(b, torch.uint8).reshape(-1)
+        if x.numel() != y.numel():
+            raise ValueError("bit strings differ in length")
+        cnt = torch.empty(1, dtype=torch.int64, device=self.device)
+        N.check(N.lib().chest_bit_errors(self._h, self._stream(), x.numel(), x.data_ptr(), y.data_ptr(), cnt.data_ptr()),
+                "chest_bit_errors")
+        return cnt
+
+
 
 _ENGINES = {}
 

@@ -210,6 +210,21 @@ int chest_tdl_apply(chest_ctx* ctx, void* stream, int32_t channel_type, int64_t 
 int chest_pack_ml_inputs(chest_ctx* ctx, void* stream, int32_t num_frames, const float* rx, const float* H_ls,
                          const float* H_true, const uint8_t* mask, int32_t normalize, float* inputs, float* targets);
 
+/* QPSK / 16-QAM helpers (src/utils.py:71-158).  M = 4 or 16, anything else -> CHEST_EINVAL (the reference raises
+ * NotImplementedError, :104, :138).  Bits are one byte per bit (0 / non-zero), most significant bit of a symbol first
+ * (:87-90, :148-151); `wide` selects complex128 (1) or complex64 (0) symbols.  Decisions are taken in float64.
+ *   chest_qam_constellation  host-side: the M points [M][2] doubles in the reference's listing order (:93-101) and
+ *                            gray_map[M] (decimal value -> point index); needs no context, either pointer may be NULL.
+ *   chest_qam_modulate       qam_modulation: symbol i = constellation[gray_map[decimal(bits[i*b .. i*b+b-1])]]
+ *   chest_qam_demodulate     qam_demodulation: nearest point (first minimum, as np.argmin), inverse Gray map, bits out
+ *   chest_bit_errors         calculate_ber's numerator: *count (DEVICE uint64) = #{i : a[i] != b[i]} */
+int chest_qam_constellation(int32_t M, double* points, int32_t* gray_map);
+int chest_qam_modulate(chest_ctx* ctx, void* stream, int32_t M, int64_t num_symbols, const uint8_t* bits, int32_t wide,
+                       void* symbols);
+int chest_qam_demodulate(chest_ctx* ctx, void* stream, int32_t M, int64_t num_symbols, int32_t wide, const void* symbols,
+                         uint8_t* bits);
+int chest_bit_errors(chest_ctx* ctx, void* stream, int64_t n, const uint8_t* a, const uint8_t* b, uint64_t* count);
+
 /* Full-covariance MMSE (MMSEEstimator(channel_covariance=R, estimate_statistics=False), :181-190).
  * prepare: W = R (R + sigma^2 I)^-1 in float64 on the device (blocked Cholesky), stored as c64
  *          W [P][P]; cov is DEVICE complex128 [P][P] (interleaved doubles).

@@ -323,6 +323,51 @@ def evaluate_estimator(H_true, H_est):
 
 
 # --------------------------------------------------------------------------------------------
+# QPSK / 16-QAM / BER helpers -- src/utils.py:71-158
+# --------------------------------------------------------------------------------------------
+def qam_tables(M):
+    """(constellation, gray_map) exactly as src/utils.py:92-103 and :125-136 build them; other orders raise
+    NotImplementedError (:104, :138)."""
+    if M == 4:
+        return np.array([1+1j, -1+1j, 1-1j, -1-1j]) / np.sqrt(2), np.array([0, 1, 3, 2])
+    if M == 16:
+        pts = np.array([-3-3j, -3-1j, -3+3j, -3+1j, -1-3j, -1-1j, -1+3j, -1+1j,
+                        3-3j, 3-1j, 3+3j, 3+1j, 1-3j, 1-1j, 1+3j, 1+1j]) / np.sqrt(10)
+        return pts, np.array([0, 1, 3, 2, 4, 5, 7, 6, 12, 13, 15, 14, 8, 9, 11, 10])
+    raise NotImplementedError(f"Modulation order {M} not implemented")
+
+
+def qam_modulate(bits, M=4):
+    """qam_modulation -- src/utils.py:71-108.  The reference indexes a Python *list* gray_map with an array (:106),
+    which raises TypeError under every NumPy release this project can run on, so the function itself cannot be
+    executed; this restates the evident intent (gray_map as an array).  The mapping is pinned through the inverse
+    the reference CAN execute: qam_demodulation(constellation points) in tests/golden/qam_kat.json."""
+    pts, gray = qam_tables(M)
+    bps = int(np.log2(M))
+    bits = np.asarray(bits)
+    n = len(bits) // bps
+    dec = bits[:n * bps].reshape(-1, bps) @ (2 ** np.arange(bps)[::-1])
+    return pts[gray[dec]]
+
+
+def qam_demodulate(symbols, M=4):
+    """qam_demodulation -- src/utils.py:111-153: nearest point by |.|, first minimum (np.argmin), inverse Gray map
+    (np.argsort(gray_map)), bits MSB first, flattened."""
+    pts, gray = qam_tables(M)
+    bps = int(np.log2(M))
+    symbols = np.asarray(symbols)
+    det = np.argmin(np.abs(symbols[:, None] - pts[None, :]), axis=1)
+    dec = np.argsort(gray)[det]
+    return ((dec[:, None] >> np.arange(bps)[::-1]) & 1).astype(int).reshape(-1)
+
+
+def bit_error_rate(tx_bits, rx_bits):
+    """calculate_ber -- src/utils.py:156-158."""
+    tx_bits, rx_bits = np.asarray(tx_bits), np.asarray(rx_bits)
+    return np.sum(tx_bits != rx_bits) / len(tx_bits)
+
+
+# --------------------------------------------------------------------------------------------
 # "faithful" mode pieces: same algorithmic structure (and cost profile) as the reference, used
 # only for the cpu_baseline timing in bench.py.
 # --------------------------------------------------------------------------------------------

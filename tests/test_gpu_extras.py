@@ -72,3 +72,72 @@ def test_pack_ml_inputs_batch_matches_per_sample_helper():
             assert np.max(np.abs(xi[i] - rx_)) < 2e-5 * np.max(np.abs(rx_))
             assert np.max(np.abs(yt[i] - ry_)) < 2e-5 * np.max(np.abs(ry_))
             assert np.array_equal(xi[i][..., 4], ds["pilot_mask"][i])
+
+
+# ---- QPSK / 16-QAM / BER helpers (src/utils.py:71-158): bit-exact integer work -------------------------------------
+U = importlib.import_module(PKG + ".utils")
+
+
+def _qam_golden(M):
+    import os
+    from conftest import GOLDEN
+    return np.load(os.path.join(GOLDEN, f"qam{M}.npz"))
+
+
+@pytest.mark.parametrize("M", [4, 16])
+def test_qam_demodulation_equals_reference_decisions(M):
+    g = _qam_golden(M)
+    out = U.qam_demodulation(g["noisy"], M)                                   # complex128 in -> float64 decisions
+    assert out.dtype == np.asarray([1]).dtype and out.shape == g["demod_noisy"].shape
+    assert np.array_equal(out, g["demod_noisy"])
+    assert np.array_equal(U.qam_demodulation(g["constellation"], M), g["demod_points"])
+    assert np.array_equal(U.qam_demodulation(g["edge"], M), g["demod_edge"])   # boundaries, NaN, inf
+    import torch
+    c64 = torch.from_numpy(g["noisy"].astype(np.complex64)).cuda()              # device tensor in -> device bits out
+    bits = U.qam_demodulation(c64, M)
+    assert bits.is_cuda and bits.dtype == torch.uint8
+    assert np.array_equal(bits.cpu().numpy(), g["demod_noisy_c64"])
+    assert U.calculate_ber(g["bits"], out) == float(g["ber"])
+
+
+@pytest.mark.parametrize("M", [4, 16])
+def test_qam_modulation_is_the_inverse_of_the_reference_demodulation(M):
+    g = _qam_golden(M)
+    bps = int(np.log2(M))
+    sym = U.qam_modulation(g["bits"].astype(int), M)
+    assert sym.dtype == np.complex128 and sym.shape == (len(g["bits"]) // bps,)
+    want = O.qam_modulate(g["bits"], M)
+    assert np.array_equal(sym.view(np.float64), want.view(np.float64))          # every bit of every point
+    assert np.array_equal(U.qam_modulation(g["bits"][:-1], M), want[:-1])        # trailing partial symbol dropped (:84-87)
+    assert U.qam_modulation(np.zeros(0, dtype=int), M).shape == (0,)
+    with pytest.raises(NotImplementedError):
+        U.qam_modulation(g["bits"], 64)
+    with pytest.raises(NotImplementedError):
+        U.qam_demodulation(want, 8)
+
+
+@pytest.mark.parametrize("M", [4, 16])
+def test_qam_round_trip_and_error_count_at_scale(M):
+    """32 M bits: demod(mod(bits)) == bits, and flipping k known positions is counted as exactly k errors, also on
+    misaligned views (the vector path needs 16-B alignment, the bytewise path must agree)."""
+    import torch
+    eng = E.get_engine(E.Geometry())
+    n = 1 << 25
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    bits = torch.randint(0, 2, (n,), dtype=torch.uint8, device="cuda", generator=gen)
+    sym = eng.qam_modulate(bits, M)
+    back = eng.qam_demodulate(sym, M)
+    assert torch.equal(back, bits)
+    assert int(eng.bit_errors(bits, back).item()) == 0
+    flip = torch.randperm(n, device="cuda", generator=gen)[:12345]
+    bad = bits.clone()
+    bad[flip] ^= 1
+    assert int(eng.bit_errors(bits, bad).item()) == 12345
+    want = int((bits[3:-6] != bad[3:-6]).sum().item())
+    a, b = bits[3:-6], bad[3:-6]                         # non-contiguous start: _dev() copies, so build raw views instead
+    cnt = torch.empty(1, dtype=torch.int64, device="cuda")
+    N = importlib.import_module(PKG + "._native")
+    N.check(N.lib().chest_bit_errors(eng._h, eng._stream(), a.numel(), a.data_ptr(), b.data_ptr(), cnt.data_ptr()), "bit_errors")
+    assert int(cnt.item()) == want
+    ber = U.calculate_ber(bits, bad)
+    assert float(ber) == 12345 / n

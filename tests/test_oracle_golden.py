@@ -119,3 +119,29 @@ def test_faithful_mode_equals_fast_mode():
     a = O.channel_frequency_response("EVA", 111.1, 1024, 72, 14, 72, 15000.0, g["u_angle"], g["u_phase"])
     b = O.channel_frequency_response_faithful("EVA", 111.1, 1024, 72, 14, 72, 15000.0, g["u_angle"], g["u_phase"])
     assert relerr(a, b) < 1e-12
+
+
+@pytest.mark.parametrize("M", [4, 16])
+def test_qam_helpers_match_reference_decisions(M):
+    """src/utils.py:111-158 run on the reference (tools/make_golden.py qam_kat): decisions for the constellation
+    points, 4 096 noisy symbols, boundary / NaN / inf inputs, and the BER.  qam_modulation itself raises TypeError in the
+    reference (list indexed by an array, :106), so the restated mapping is pinned as the inverse of these decisions."""
+    g = np.load(os.path.join(GOLDEN, f"qam{M}.npz"))
+    kat = json.load(open(os.path.join(GOLDEN, "qam_kat.json")))
+    assert kat["modulation_executable"] is False
+    pts, gray = O.qam_tables(M)
+    assert np.array_equal(pts.view(np.float64), g["constellation"].view(np.float64)) and np.array_equal(gray, g["gray_map"])
+    assert np.array_equal(O.qam_demodulate(g["constellation"], M), g["demod_points"])
+    assert np.array_equal(O.qam_demodulate(g["noisy"], M), g["demod_noisy"])
+    assert np.array_equal(O.qam_demodulate(g["noisy"].astype(np.complex64).astype(np.complex128), M), g["demod_noisy_c64"])
+    with np.errstate(invalid="ignore"):
+        assert np.array_equal(O.qam_demodulate(g["edge"], M), g["demod_edge"])
+    bps = int(np.log2(M))
+    # the reference's decision for point gray_map[d] spells d: modulation is its inverse
+    dec = g["demod_points"].reshape(M, bps) @ (2 ** np.arange(bps)[::-1])
+    assert np.array_equal(gray[dec], np.arange(M))
+    sym = O.qam_modulate(g["bits"], M)
+    assert np.array_equal(O.qam_demodulate(sym, M), g["bits"])
+    assert O.bit_error_rate(g["bits"], g["demod_noisy"]) == float(g["ber"]) == kat["cases"][str(M)]["ber_noisy"]
+    with pytest.raises(NotImplementedError):
+        O.qam_tables(64)

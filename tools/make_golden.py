@@ -274,13 +274,65 @@ def cubic_cases(ref, out_dir):
         print(f"{name:34s} ok  {os.path.getsize(os.path.join(out_dir, name + '.npz')) / 1024:.0f} KiB")
 
 
+def qam_kat(ref_root, out_dir):
+    """QPSK / 16-QAM helpers of src/utils.py.  qam_modulation cannot be executed (it indexes a list
+    with an array, TypeError), so the mapping is pinned through qam_demodulation: its decisions for the exact
+    constellation points, for seeded noisy symbols (complex128 and their complex64 rounding) and for boundary /
+    non-finite inputs; calculate_ber on the resulting bit strings."""
+    import utils as ru
+    out = {"numpy": np.__version__, "cases": {}}
+    try:
+        ru.qam_modulation(np.array([0, 1, 1, 0]), 4)
+        out["modulation_executable"] = True
+    except TypeError as e:
+        out["modulation_executable"] = False
+        out["modulation_error"] = type(e).__name__
+    for M in (4, 16):
+        pts, gray = O.qam_tables(M)
+        bps = int(np.log2(M))
+        rs = np.random.RandomState(700 + M)
+        n = 4096
+        bits = rs.randint(0, 2, n * bps)
+        sym = O.qam_modulate(bits, M)
+        noisy = sym + (rs.randn(n) + 1j * rs.randn(n)) * 0.25
+        edge = np.array([0, 1e-300, -1e-300j, 2 / np.sqrt(10), 2j / np.sqrt(10), -2 / np.sqrt(10) + 0.1j, 5 + 5j, -7 - 0.2j,
+                         complex(np.nan, 0), complex(0, np.nan), complex(np.inf, 1), complex(-np.inf, -np.inf)])
+        with np.errstate(invalid="ignore"):
+            d_pts = ru.qam_demodulation(pts, M)
+            d_clean = ru.qam_demodulation(sym, M)
+            d_noisy = ru.qam_demodulation(noisy, M)
+            d_noisy32 = ru.qam_demodulation(noisy.astype(np.complex64).astype(np.complex128), M)
+            d_edge = ru.qam_demodulation(edge, M)
+        assert np.array_equal(d_clean, bits), "restated modulation is not the inverse of the reference demodulation"
+        for a, b in ((d_pts, O.qam_demodulate(pts, M)), (d_noisy, O.qam_demodulate(noisy, M))):
+            assert np.array_equal(a, b)
+        with np.errstate(invalid="ignore"):
+            assert np.array_equal(d_edge, O.qam_demodulate(edge, M))
+        ber = float(ru.calculate_ber(bits, d_noisy))
+        assert ber == float(O.bit_error_rate(bits, d_noisy))
+        np.savez_compressed(os.path.join(out_dir, f"qam{M}.npz"), bits=bits.astype(np.uint8), noisy=noisy, edge=edge,
+                            demod_points=d_pts.astype(np.uint8), demod_noisy=d_noisy.astype(np.uint8),
+                            demod_noisy_c64=d_noisy32.astype(np.uint8), demod_edge=d_edge.astype(np.uint8),
+                            constellation=pts, gray_map=gray, ber=np.float64(ber))
+        out["cases"][str(M)] = {"n": n, "ber_noisy": ber, "bit_errors": int(np.sum(bits != d_noisy)),
+                                "demod_points": [int(v) for v in d_pts]}
+        print(f"qam{M}: ber {ber:.5f}, edge bits {d_edge.tolist()}")
+    with open(os.path.join(out_dir, "qam_kat.json"), "w") as f:
+        json.dump(out, f, indent=1)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reference", default="/root/reference")
     ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden"))
     ap.add_argument("--only-cubic", action="store_true", help="write only the cubic_*.npz fixtures")
+    ap.add_argument("--only-qam", action="store_true", help="write only the qam*.npz / qam_kat.json fixtures")
     args = ap.parse_args()
     sys.path.insert(0, os.path.join(args.reference, "src"))
+    if args.only_qam:
+        os.makedirs(args.out, exist_ok=True)
+        qam_kat(args.reference, args.out)
+        return
     import baseline_estimators as be
     import channel_simulator as cs
     ref = (cs, be)
@@ -318,6 +370,7 @@ def main():
     del e
     rng_kat(ref, args.out)
     dataset_kat(args.reference, args.out)
+    qam_kat(args.reference, args.out)
 
 
 if __name__ == "__main__":
