@@ -32,7 +32,7 @@ WORKLOADS = {
     "cfg3_4x4_etu_mmse": (4, 4, 1024, 72, 600, "ETU", 370.4, 10.0, 0.10, 6250),
     "cfg1_siso_epa_ls": (1, 1, 1024, 72, 600, "EPA", 5.56, 10.0, 0.10, 10000),
 }
-PATTERN_GROUP = 1024           # frames that share one pilot pattern / interpolation plan
+PATTERN_GROUP = 1024           # frames that share one pilot pattern / interpolation plan (--pattern-group 1: one per frame)
 
 
 def algorithmic_bytes_per_frame(S, nsc, T, R, P, n_est=2):
@@ -104,6 +104,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="cfg2_2x2_eva_ls_mmse", choices=sorted(WORKLOADS))
     ap.add_argument("--frames", type=int, default=None, help="frames per step per GPU (default: the config's)")
+    ap.add_argument("--pattern-group", type=int, default=PATTERN_GROUP,
+                    help="frames sharing one pilot pattern + interpolation plan; 1 = a new random pattern per frame as the "
+                         "reference draws them (plans are built on the host with Qhull BEFORE the timed region)")
+    ap.add_argument("--plan-workers", type=int, default=0, help="host processes for plan building (0 = min(16, cores))")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--with-metrics", action="store_true", help="also produce the fused error sums inside the timed step")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
@@ -139,14 +143,26 @@ def main():
     P = int(G * dens)
 
     # ---- inputs resident in HBM before the timed region: patterns, plans, descriptors -------------
-    npat = (F + PATTERN_GROUP - 1) // PATTERN_GROUP
-    slots = []
+    group = max(1, args.pattern_group)
+    npat = (F + group - 1) // group
+    pils = []
     for gidx in range(npat):
         rs = np.random.RandomState(2024 + gidx)                # legacy shuffle, as PilotPattern does
         perm = np.arange(G)
         rs.shuffle(perm)
-        slots.append(eng.pattern_slot(np.sort(perm[:P]), "linear"))
-    slot_of_frame = np.asarray(slots, dtype=np.int32)[np.arange(F) // PATTERN_GROUP]
+        pils.append(np.sort(perm[:P]))
+    t_plan = time.perf_counter()
+    workers = args.plan_workers or min(16, os.cpu_count() or 1)
+    if npat >= 4 * workers:                                       # Qhull + point location, ~10-25 ms per pattern per core
+        IP = importlib.import_module(PKG + ".interp_plan")
+        plans = IP.build_plans_parallel(pils, S, nsc, "linear", workers)
+    else:
+        workers, plans = 1, [None] * npat
+    eng.max_cached_patterns = max(eng.max_cached_patterns, npat + 8)
+    slots = [eng.pattern_slot(pil, "linear", plan=pl) for pil, pl in zip(pils, plans)]
+    t_plan = time.perf_counter() - t_plan
+    del plans
+    slot_of_frame = np.asarray(slots, dtype=np.int32)[np.arange(F) // group]
     descs = E.make_descs(ct, fd, snr, slot_of_frame, n=F)
     d_dev = torch.from_numpy(descs.view(np.uint8).copy()).to(eng.device)
     names = ["tx", "rx", "H", "H_ls", "H_mmse", "pilot_symbols", "pilot_mask"]
@@ -197,13 +213,15 @@ def main():
 
     if rank == 0:
         bytes_frame = algorithmic_bytes_per_frame(S, nsc, T, R, P, 2)
+        if group == 1:          # a plan of its own per frame has to be read: 16-B record per RE + 4-B pilot index
+            bytes_frame += 16 * G + 4 * P
         achieved = bytes_frame * F / (kern_ms * 1e-3) / 1e9
         traffic = None
         tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tfile):
             try:
                 rec = json.load(open(tfile))
-                if rec.get("workload") == args.workload and rec.get("frames") == F:
+                if rec.get("workload") == args.workload and rec.get("frames") == F and group == PATTERN_GROUP:
                     traffic = rec.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
@@ -214,7 +232,8 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": args.workload, "frames_per_step_per_gpu": F, "mimo": f"{T}x{R}", "fft_size": N,
                        "channel": ct, "doppler_hz": fd, "snr_db": snr, "pilot_density": dens, "pilots": P,
-                       "estimators": "LS(linear)+MMSE(diag)", "pattern_group": PATTERN_GROUP,
+                       "estimators": "LS(linear)+MMSE(diag)", "pattern_group": group, "patterns": npat,
+                       "host_plan_build_s": round(t_plan, 2), "host_plan_workers": workers,
                        "rng": "Philox4x32-10 on device", "outputs": names, "parallelism": f"frames sharded x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "frame_kernel",
