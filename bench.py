@@ -106,7 +106,7 @@ def main():
     ap.add_argument("--frames", type=int, default=None, help="frames per step per GPU (default: the config's)")
     ap.add_argument("--pattern-group", type=int, default=PATTERN_GROUP,
                     help="frames sharing one pilot pattern + interpolation plan; 1 = a new random pattern per frame as the "
-                         "reference draws them (plans are built on the host with Qhull BEFORE the timed region)")
+                         "reference draws them (Qhull triangulation on the host, plan on the device, BEFORE the timed region)")
     ap.add_argument("--plan-workers", type=int, default=0, help="host processes for plan building (0 = min(16, cores))")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--with-metrics", action="store_true", help="also produce the fused error sums inside the timed step")
@@ -153,9 +153,9 @@ def main():
         pils.append(np.sort(perm[:P]))
     t_plan = time.perf_counter()
     workers = args.plan_workers or min(16, os.cpu_count() or 1)
-    if npat >= 4 * workers:                                       # Qhull + point location, ~10-25 ms per pattern per core
+    if npat >= 4 * workers:                 # Qhull Delaunay on the host (~3 ms per pattern per core); point location on the GPU
         IP = importlib.import_module(PKG + ".interp_plan")
-        plans = IP.build_plans_parallel(pils, S, nsc, "linear", workers)
+        plans = IP.triangulations_parallel(pils, S, nsc, workers)
     else:
         workers, plans = 1, [None] * npat
     eng.max_cached_patterns = max(eng.max_cached_patterns, npat + 8)

@@ -53,6 +53,8 @@ SIGNATURES = {
     "chest_get_used_indices": (_i32, [_vp, C.POINTER(_i32), C.POINTER(_i64)]),
     "chest_get_tap_table": (_i32, [_vp, _i32, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(C.c_double)]),
     "chest_pattern_set": (_i32, [_vp, _i32, _vp, _i32, _vp, _vp]),
+    "chest_pattern_set_triangulation": (_i32, [_vp, _i32, _vp, _i32, _vp, _i32]),
+    "chest_pattern_get_plan": (_i32, [_vp, _i32, _vp, _vp]),
     "chest_pattern_num_pilots": (_i32, [_vp, _i32]),
     "chest_get_status": (_i32, [_vp, C.POINTER(_i32)]),
     "chest_profile_begin": (_i32, [_vp, _i32]),

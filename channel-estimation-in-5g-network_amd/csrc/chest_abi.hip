@@ -218,12 +218,11 @@ int chest_get_tap_table(chest_ctx* ctx, int32_t type, int32_t* num_paths, int32_
     return CHEST_OK;
 }
 
-int chest_pattern_set(chest_ctx* ctx, int32_t slot, const int32_t* pilot_idx, int32_t P, const uint16_t* plan_idx,
-                      const float* plan_w) {
-    if (!ctx || slot < 0 || slot > (1 << 20) || pilot_idx == nullptr) { set_error("chest_pattern_set: bad argument"); return CHEST_EINVAL; }
+// shared body of chest_pattern_set / chest_pattern_set_triangulation
+static int pattern_set_impl(chest_ctx* ctx, int32_t slot, const int32_t* pilot_idx, int32_t P, const uint16_t* plan_idx,
+                            const float* plan_w, const int32_t* simplices, int32_t ns) {
     const int G = ctx->fp.G;
     if (P < 1 || P > G) { set_error("chest_pattern_set: num_pilots %d out of range (1..%d)", P, G); return CHEST_EINVAL; }
-    if ((plan_idx == nullptr) != (plan_w == nullptr)) { set_error("plan_idx/plan_w must be given together"); return CHEST_EINVAL; }
     for (int i = 0; i < P; ++i) {
         if (pilot_idx[i] < 0 || pilot_idx[i] >= G || (i > 0 && pilot_idx[i] <= pilot_idx[i - 1])) {
             set_error("chest_pattern_set: pilot_idx must be sorted, unique and inside the %d-element grid", G);
@@ -233,6 +232,13 @@ int chest_pattern_set(chest_ctx* ctx, int32_t slot, const int32_t* pilot_idx, in
     if (plan_idx)
         for (size_t i = 0; i < (size_t)3 * G; ++i)
             if (plan_idx[i] >= P) { set_error("chest_pattern_set: plan index %u >= num_pilots %d", plan_idx[i], P); return CHEST_EINVAL; }
+    if (simplices)
+        for (size_t i = 0; i < (size_t)3 * ns; ++i)
+            if (simplices[i] < 0 || simplices[i] >= P) {
+                set_error("chest_pattern_set_triangulation: simplex vertex %d outside 0..%d", simplices[i], P - 1);
+                return CHEST_EINVAL;
+            }
+    const bool with_plan = plan_idx != nullptr || simplices != nullptr;
     CHEST_HIP(hipSetDevice(ctx->cfg.device));
     // draw slot of every resource element: i-th pilot <-> i-th True of the row-major mask
     // (insert_pilots, src/channel_simulator.py:249-252); data symbols follow in row-major order.
@@ -256,33 +262,80 @@ int chest_pattern_set(chest_ctx* ctx, int32_t slot, const int32_t* pilot_idx, in
             recs[g] = Rec{w0, w1, i0 | (i1 << 16), i2 | (valid << 16)};
         }
     }
+    // block layout: slot[G] u16 | pilot_idx[P] | simplices[ns][3] (triangulation path) | plan[G] records (last, so the
+    // triangulation path uploads everything before it in one copy and the device fills the plan)
     const size_t o_slot = 0;
-    const size_t o_plan = up16(o_slot + (size_t)G * 2);
-    const size_t o_pil = up16(o_plan + (plan_idx ? (size_t)G * sizeof(Rec) : 0));
-    const size_t total = up16(o_pil + (size_t)P * 4);
+    const size_t o_pil = up16(o_slot + (size_t)G * 2);
+    const size_t o_simp = up16(o_pil + (size_t)P * 4);
+    const size_t o_plan = (o_simp + (simplices ? (size_t)ns * 12 : 0) + 255) & ~(size_t)255;
+    const size_t total = up16(o_plan + (with_plan ? (size_t)G * sizeof(Rec) : 0));
+    const size_t upload = plan_idx ? total : o_plan;
     unsigned char* blk = nullptr;
     CHEST_HIP(hipMalloc((void**)&blk, total));
-    std::vector<unsigned char> host(total, 0);
+    std::vector<unsigned char> host(upload, 0);
     memcpy(host.data() + o_slot, slots.data(), (size_t)G * 2);
-    if (plan_idx) memcpy(host.data() + o_plan, recs.data(), (size_t)G * sizeof(Rec));
     memcpy(host.data() + o_pil, pilot_idx, (size_t)P * 4);
-    if (hipMemcpy(blk, host.data(), total, hipMemcpyHostToDevice) != hipSuccess) {
+    if (simplices) memcpy(host.data() + o_simp, simplices, (size_t)ns * 12);
+    if (plan_idx) memcpy(host.data() + o_plan, recs.data(), (size_t)G * sizeof(Rec));
+    if (hipMemcpy(blk, host.data(), upload, hipMemcpyHostToDevice) != hipSuccess) {
         (void)hipFree(blk);
         set_error("pattern upload failed");
         return CHEST_EHIP;
+    }
+    if (simplices) {
+        // point location + barycentric weights on the device (plan_kernels.hip); synchronous like the uploads around it
+        int rc = launch_plan_locate(ctx, nullptr, (const int32_t*)(blk + o_pil), (const int32_t*)(blk + o_simp), ns, blk + o_plan);
+        if (rc == CHEST_OK && hipStreamSynchronize(nullptr) != hipSuccess) { set_error("plan construction failed"); rc = CHEST_EHIP; }
+        if (rc != CHEST_OK) { (void)hipFree(blk); return rc; }
     }
     if ((size_t)slot >= ctx->patterns.size()) ctx->patterns.resize(slot + 1);
     PatternHost& ph = ctx->patterns[slot];
     if (ph.block) { CHEST_HIP(hipDeviceSynchronize()); CHEST_HIP(hipFree(ph.block)); }
     ph.block = blk;
     ph.dev.slot = (const uint16_t*)(blk + o_slot);
-    ph.dev.plan = plan_idx ? (const void*)(blk + o_plan) : nullptr;
+    ph.dev.plan = with_plan ? (const void*)(blk + o_plan) : nullptr;
     ph.dev.pilot_idx = (const int32_t*)(blk + o_pil);
     ph.dev.P = P;
     // table entries between the old size and `slot` stay zero (slot == nullptr -> "not set")
-    {
-        int rc = upload_pattern_table_entry(ctx, slot);
-        if (rc != CHEST_OK) return rc;
+    return upload_pattern_table_entry(ctx, slot);
+}
+
+int chest_pattern_set(chest_ctx* ctx, int32_t slot, const int32_t* pilot_idx, int32_t P, const uint16_t* plan_idx,
+                      const float* plan_w) {
+    if (!ctx || slot < 0 || slot > (1 << 20) || pilot_idx == nullptr) { set_error("chest_pattern_set: bad argument"); return CHEST_EINVAL; }
+    if ((plan_idx == nullptr) != (plan_w == nullptr)) { set_error("plan_idx/plan_w must be given together"); return CHEST_EINVAL; }
+    return pattern_set_impl(ctx, slot, pilot_idx, P, plan_idx, plan_w, nullptr, 0);
+}
+
+int chest_pattern_set_triangulation(chest_ctx* ctx, int32_t slot, const int32_t* pilot_idx, int32_t P, const int32_t* simplices,
+                                    int32_t num_simplices) {
+    if (!ctx || slot < 0 || slot > (1 << 20) || pilot_idx == nullptr || simplices == nullptr || num_simplices < 1 ||
+        num_simplices > (1 << 22)) {
+        set_error("chest_pattern_set_triangulation: bad argument");
+        return CHEST_EINVAL;
+    }
+    return pattern_set_impl(ctx, slot, pilot_idx, P, nullptr, nullptr, simplices, num_simplices);
+}
+
+int chest_pattern_get_plan(chest_ctx* ctx, int32_t slot, uint16_t* plan_idx, float* plan_w) {
+    if (!ctx || slot < 0 || (size_t)slot >= ctx->patterns.size() || ctx->patterns[slot].block == nullptr) {
+        set_error("pattern slot %d is not set", slot);
+        return CHEST_ESTATE;
+    }
+    if (ctx->patterns[slot].dev.plan == nullptr) { set_error("pattern slot %d has no interpolation plan", slot); return CHEST_ESTATE; }
+    if (!plan_idx || !plan_w) { set_error("chest_pattern_get_plan: null output"); return CHEST_EINVAL; }
+    const int G = ctx->fp.G;
+    struct Rec { float w0, w1; uint32_t i01, i2v; };
+    std::vector<Rec> recs(G);
+    CHEST_HIP(hipSetDevice(ctx->cfg.device));
+    CHEST_HIP(hipMemcpy(recs.data(), ctx->patterns[slot].dev.plan, (size_t)G * sizeof(Rec), hipMemcpyDeviceToHost));
+    for (int g = 0; g < G; ++g) {
+        const Rec& r = recs[g];
+        const bool valid = (r.i2v >> 16) != 0;
+        plan_idx[g] = (uint16_t)(r.i01 & 0xFFFFu); plan_idx[(size_t)G + g] = (uint16_t)(r.i01 >> 16);
+        plan_idx[2 * (size_t)G + g] = (uint16_t)(r.i2v & 0xFFFFu);
+        plan_w[g] = r.w0; plan_w[(size_t)G + g] = r.w1;
+        plan_w[2 * (size_t)G + g] = valid ? 1.0f - r.w0 - r.w1 : 0.0f;      // as the kernels evaluate it
     }
     return CHEST_OK;
 }

@@ -72,6 +72,10 @@ def make_descs(channel_type, doppler_hz, snr_db, pattern_slot, n=None):
     return d
 
 
+_NP_DTYPE = {torch.complex64: np.complex64, torch.complex128: np.complex128, torch.float32: np.float32,
+             torch.float64: np.float64, torch.uint8: np.uint8, torch.int32: np.int32, torch.int64: np.int64}
+
+
 class Engine:
     def __init__(self, geometry: Geometry, device=None):
         if not torch.cuda.is_available():
@@ -121,27 +125,45 @@ class Engine:
 
     # ---- patterns -----------------------------------------------------------------------------------
     def set_pattern(self, slot: int, pilot_idx, plan=None):
-        """Upload a sorted flat pilot index list (PilotPattern.pilot_indices) and optionally its plan."""
+        """Upload a sorted flat pilot index list (PilotPattern.pilot_indices) and optionally its interpolation plan:
+        either a host plan ``(idx uint16[3,G], w float32[3,G])`` or Delaunay simplices ``int32[n,3]`` from which the
+        device builds the 'linear' plan itself."""
         pi = np.ascontiguousarray(pilot_idx, dtype=np.int32)
-        if plan is None:
-            pidx = pw = None
+        if isinstance(plan, np.ndarray):
+            simp = np.ascontiguousarray(plan, dtype=np.int32)
+            if simp.ndim != 2 or simp.shape[1] != 3 or simp.shape[0] < 1:
+                raise ValueError("simplices must be an (n, 3) integer array")
+            N.check(N.lib().chest_pattern_set_triangulation(self._h, int(slot), pi.ctypes.data, len(pi), simp.ctypes.data,
+                                                            simp.shape[0]), "chest_pattern_set_triangulation")
         else:
-            pidx = np.ascontiguousarray(plan[0], dtype=np.uint16)
-            pw = np.ascontiguousarray(plan[1], dtype=np.float32)
-            if pidx.shape != (3, self.geom.grid) or pw.shape != (3, self.geom.grid):
-                raise ValueError(f"plan must be two (3, {self.geom.grid}) arrays")
-        N.check(N.lib().chest_pattern_set(self._h, int(slot), pi.ctypes.data, len(pi),
-                                          None if pidx is None else pidx.ctypes.data,
-                                          None if pw is None else pw.ctypes.data), "chest_pattern_set")
+            if plan is None:
+                pidx = pw = None
+            else:
+                pidx = np.ascontiguousarray(plan[0], dtype=np.uint16)
+                pw = np.ascontiguousarray(plan[1], dtype=np.float32)
+                if pidx.shape != (3, self.geom.grid) or pw.shape != (3, self.geom.grid):
+                    raise ValueError(f"plan must be two (3, {self.geom.grid}) arrays")
+            N.check(N.lib().chest_pattern_set(self._h, int(slot), pi.ctypes.data, len(pi),
+                                              None if pidx is None else pidx.ctypes.data,
+                                              None if pw is None else pw.ctypes.data), "chest_pattern_set")
         self._slot_P[int(slot)] = len(pi)
         self._next_slot = max(self._next_slot, int(slot) + 1)
         return int(slot)
+
+    def get_plan(self, slot: int):
+        """The slot's plan as host arrays (idx uint16[3,G], w float32[3,G])."""
+        G = self.geom.grid
+        idx = np.empty((3, G), dtype=np.uint16)
+        w = np.empty((3, G), dtype=np.float32)
+        N.check(N.lib().chest_pattern_get_plan(self._h, int(slot), idx.ctypes.data, w.ctypes.data), "chest_pattern_get_plan")
+        return idx, w
 
     def pattern_slot(self, pilot_idx, method="linear", with_plan=True, plan=None):
         """Slot for a pattern, uploading it (and building its plan) on first use.  At most
         ``max_cached_patterns`` auto-managed patterns stay resident; the least recently used slot is
         re-used after that (single-frame drop-in calls draw a new random pattern every frame).  ``plan`` may carry a
-        plan built elsewhere (interp_plan.build_plans_parallel)."""
+        host plan or Delaunay simplices built elsewhere (interp_plan.build_plans_parallel / triangulations_parallel).
+        'linear': Qhull triangulation on the host, point location + weights on the device; 'nearest': host cKDTree."""
         key = interp_plan.pattern_key(pilot_idx, method if with_plan else None)
         slot = self._slots.get(key)
         if slot is not None:
@@ -150,7 +172,10 @@ class Engine:
         if with_plan and plan is None:
             S, nsc = self.geom.num_symbols, self.geom.num_sc
             ps, pk = np.unravel_index(np.asarray(pilot_idx, dtype=np.int64), (S, nsc))
-            plan = interp_plan.build_plan(ps, pk, S, nsc, method)
+            if method == "linear":
+                plan = interp_plan.linear_triangulation(ps, pk)
+            else:
+                plan = interp_plan.build_plan(ps, pk, S, nsc, method)
         if len(self._slots) >= self.max_cached_patterns:
             old_key = next(iter(self._slots))
             slot = self._slots.pop(old_key)                   # chest_pattern_set syncs before freeing it
@@ -189,7 +214,9 @@ class Engine:
         """Host array / tensor -> contiguous device tensor of `dtype` (no copy if already there)."""
         if isinstance(a, torch.Tensor):
             return a.to(device=self.device, dtype=dtype).contiguous()
-        return torch.from_numpy(np.ascontiguousarray(a)).to(device=self.device, dtype=dtype).contiguous()
+        # convert on the host with NumPy (single-threaded), then a plain copy: a dtype-converting Tensor.to() on a CPU
+        # tensor starts torch's intra-op thread pool, which on a CPU-quota'd box costs milliseconds per call
+        return torch.from_numpy(np.ascontiguousarray(a, dtype=_NP_DTYPE[dtype])).to(device=self.device)
 
     def _c64(self, a):
         return self._dev(a, torch.complex64)

@@ -11,6 +11,12 @@ extracted from ``scipy.spatial.Delaunay`` itself.  ``'nearest'`` is a cKDTree qu
 (``NearestNDInterpolator``), a plan with weights (1, 0, 0).
 
 A plan is ``(idx uint16[3, G], w float32[3, G])`` with G = S*nsc in row-major grid order.
+
+For ``'linear'`` the engine's default is to take only the triangulation from the host
+(``linear_triangulation``: Qhull, ~3 ms per full-size pattern) and to do the point location and the
+barycentric weights on the GPU (``chest_pattern_set_triangulation``); ``linear_plan`` -- SciPy's own
+``find_simplex`` + ``transform``, ~45 ms -- stays as the cross-check and for callers that want the plan
+on the host.
 """
 from __future__ import annotations
 
@@ -25,6 +31,15 @@ _CACHE_MAX = 256
 def _grid_points(S, nsc):
     ss, kk = np.meshgrid(np.arange(S), np.arange(nsc), indexing="ij")
     return np.column_stack([ss.ravel(), kk.ravel()]).astype(np.float64)
+
+
+def linear_triangulation(pilot_sym, pilot_sc):
+    """``scipy.spatial.Delaunay(points).simplices`` (int32 [n, 3] pilot ordinals) of the pilot positions, i.e. the
+    triangulation griddata's LinearNDInterpolator builds.  Raises scipy's QhullError for degenerate pilot sets
+    (fewer than 3 pilots, all collinear), like the reference does."""
+    from scipy.spatial import Delaunay
+    pts = np.column_stack([np.asarray(pilot_sym), np.asarray(pilot_sc)]).astype(np.float64)
+    return np.ascontiguousarray(Delaunay(pts).simplices, dtype=np.int32)
 
 
 def linear_plan(pilot_sym, pilot_sc, S, nsc):
@@ -103,6 +118,22 @@ def build_plan(pilot_sym, pilot_sc, S, nsc, method="linear"):
             _CACHE.pop(next(iter(_CACHE)))
         _CACHE[key] = hit
     return hit
+
+
+def _tri_job(args):
+    pilot_idx, S, nsc = args
+    ps, pk = np.unravel_index(np.asarray(pilot_idx, dtype=np.int64), (S, nsc))
+    return linear_triangulation(ps, pk)
+
+
+def triangulations_parallel(pilot_idx_list, S, nsc, workers=0):
+    """Delaunay simplices for many patterns, optionally in a spawn-context process pool; input order."""
+    jobs = [(np.asarray(p, dtype=np.int64), S, nsc) for p in pilot_idx_list]
+    if workers and workers > 1 and len(jobs) > 1:
+        import multiprocessing as mp
+        with mp.get_context("spawn").Pool(min(workers, len(jobs))) as pool:
+            return pool.map(_tri_job, jobs, chunksize=max(1, len(jobs) // (4 * workers)))
+    return [_tri_job(j) for j in jobs]
 
 
 def _plan_job(args):

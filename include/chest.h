@@ -128,6 +128,16 @@ int chest_get_tap_table(chest_ctx* ctx, int32_t channel_type, int32_t* num_paths
  *             'nearest' = (1,0,0)); both may be NULL for simulation-only use. */
 int chest_pattern_set(chest_ctx* ctx, int32_t slot, const int32_t* pilot_idx, int32_t num_pilots,
                       const uint16_t* plan_idx, const float* plan_w);
+/* Same upload, but the griddata('linear') plan is built ON THE DEVICE from the pattern's Delaunay triangulation:
+ * simplices HOST int32[num_simplices][3] pilot ordinals = scipy.spatial.Delaunay(pilot positions).simplices, what
+ * LinearNDInterpolator builds at src/baseline_estimators.py:74-79 via griddata.  (The triangulation must be Qhull's: its
+ * choice among co-circular lattice points decides the interpolated values.)  Each resource element is located with
+ * exact integer orientation tests -- hull boundary counts as inside, zero-area simplices are skipped -- and gets the
+ * simplex's three ordinals and barycentric weights; weights 0 outside the hull. */
+int chest_pattern_set_triangulation(chest_ctx* ctx, int32_t slot, const int32_t* pilot_idx, int32_t num_pilots,
+                                    const int32_t* simplices, int32_t num_simplices);
+/* Read a slot's plan back in chest_pattern_set's layout: HOST plan_idx uint16[3][G], plan_w float[3][G]. */
+int chest_pattern_get_plan(chest_ctx* ctx, int32_t slot, uint16_t* plan_idx, float* plan_w);
 int chest_pattern_num_pilots(chest_ctx* ctx, int32_t slot);
 /* Device-side error word set by kernels that met a bad frame descriptor (1) or a pattern without a
  * plan (2); reading it synchronises the device and clears it. HOST out. */

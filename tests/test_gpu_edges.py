@@ -123,3 +123,45 @@ def test_pattern_cache_lru_reuses_slots():
     m = np.zeros(994, bool); m[pats[-1]] = True
     assert np.array_equal(out["pilot_mask"][0].cpu().numpy().ravel().astype(bool), m)
     eng.close()
+
+
+IP = importlib.import_module(PKG + ".interp_plan")
+
+
+def _plan_apply(idx, w, vals):
+    """Plan applied to a few pilot-value vectors [P, n] -> [G, n] (float64)."""
+    return sum(w[c].astype(np.float64)[:, None] * vals[idx[c].astype(int)] for c in range(3))
+
+
+@pytest.mark.parametrize("fft,cp,U,P,seed", [(1024, 72, 600, 838, 11), (1024, 72, 600, 83, 12), (1024, 72, 72, 9, 13),
+                                             (2048, 144, 1200, 1678, 14), (2048, 144, 1200, 8393, 15)])
+def test_device_built_linear_plan_equals_scipy_plan(fft, cp, U, P, seed):
+    """chest_pattern_set_triangulation: point location + barycentric weights on the GPU from Qhull's simplices.  As an
+    operator on the pilot values the plan equals scipy's find_simplex/transform plan (= griddata 'linear'), the same
+    elements fall outside the hull, and away from shared edges even the three ordinals agree.  2048-FFT cases stage the
+    simplices through LDS in several tiles (3 300 and 16 000 simplices)."""
+    geom = E.Geometry(fft_size=fft, cp_length=cp, num_symbols=14, useful_subcarriers=U, num_tx=1, num_rx=1)
+    eng = E.Engine(geom, 0)
+    S, nsc, G = geom.num_symbols, geom.num_sc, geom.grid
+    rs = np.random.RandomState(seed)
+    pil = np.sort(rs.permutation(G)[:P])
+    ps, pk = np.unravel_index(pil, (S, nsc))
+    simp = IP.linear_triangulation(ps, pk)
+    slot_dev = eng.set_pattern(0, pil, simp)
+    idx_d, w_d = eng.get_plan(slot_dev)
+    idx_h, w_h = IP.linear_plan(ps, pk, S, nsc)
+    assert np.array_equal(np.abs(w_d).sum(0) > 0, np.abs(w_h).sum(0) > 0)            # same hull
+    vals = rs.randn(P, 8)
+    assert np.max(np.abs(_plan_apply(idx_d, w_d, vals) - _plan_apply(idx_h, w_h, vals))) < 2e-6   # f32 weights, |vals| ~ 4
+    interior = (w_h.min(0) > 1e-6)                                                    # strictly inside one simplex
+    assert interior.sum() > 0
+    assert np.array_equal(np.sort(idx_d[:, interior], 0), np.sort(idx_h[:, interior], 0))
+    # and through the estimator: same H_ls from either plan
+    slot_host = eng.set_pattern(1, pil, (idx_h, w_h))
+    rx = (rs.randn(2, S, 1, 1, nsc) + 1j * rs.randn(2, S, 1, 1, nsc)).astype(np.complex64)
+    xp = np.exp(2j * np.pi * rs.rand(P)).astype(np.complex64)
+    a = eng.estimate(rx, xp, slot_dev).cpu().numpy()
+    b = eng.estimate(rx, xp, slot_host).cpu().numpy()
+    assert relerr(a, b) < 1e-6
+    with pytest.raises(Exception):
+        eng.set_pattern(2, pil, np.array([[0, 1, P]], dtype=np.int32))               # vertex outside 0..P-1

@@ -166,3 +166,42 @@ def test_parallel_plan_builder_equals_serial():
         ps, pk = np.unravel_index(p, (14, 71))
         ref = ip.build_plan(ps, pk, 14, 71, "linear")
         assert np.array_equal(i0, ref[0]) and np.array_equal(w0, ref[1])
+
+
+def _locate_exact(ps, pk, simp, S, nsc):
+    """NumPy model of plan_locate_kernel: first simplex (in Qhull's order) whose exact integer orientation tests contain
+    the resource element; zero-area simplices skipped; returns dense operator rows [G, P]."""
+    G, P = S * nsc, len(ps)
+    A = np.zeros((G, P))
+    gs, gk = np.divmod(np.arange(G), nsc)
+    done = np.zeros(G, bool)
+    for a, b, c in simp:
+        x0, y0, x1, y1, x2, y2 = ps[a] - gs, pk[a] - gk, ps[b] - gs, pk[b] - gk, ps[c] - gs, pk[c] - gk
+        n0, n1, n2 = x1 * y2 - y1 * x2, x2 * y0 - y2 * x0, x0 * y1 - y0 * x1
+        den = n0 + n1 + n2
+        sgn = np.sign(den)
+        hit = (~done) & (den != 0) & (n0 * sgn >= 0) & (n1 * sgn >= 0) & (n2 * sgn >= 0)
+        for col, num in ((a, n0), (b, n1), (c, n2)):
+            A[hit, col] += (num[hit] / den[hit])
+        done |= hit
+    return A, done
+
+
+@pytest.mark.parametrize("S,nsc,P,seed", [(14, 71, 99, 0), (14, 71, 9, 1), (14, 599, 838, 2), (14, 599, 83, 3), (3, 40, 5, 6)])
+def test_exact_integer_point_location_reproduces_scipy_plan(S, nsc, P, seed):
+    """The device builds the 'linear' plan from Qhull's simplices with exact integer tests; as an operator on the pilot
+    values it must equal scipy's find_simplex + transform plan (= griddata), including which elements lie outside the hull."""
+    rs = np.random.RandomState(seed)
+    pil = np.sort(rs.permutation(S * nsc)[:P])
+    ps, pk = np.unravel_index(pil, (S, nsc))
+    simp = ip.linear_triangulation(ps, pk)
+    assert simp.dtype == np.int32 and simp.shape[1] == 3
+    A, inside = _locate_exact(ps, pk, simp, S, nsc)
+    idx, w = ip.linear_plan(ps, pk, S, nsc)
+    B = np.zeros_like(A)
+    for c in range(3):
+        np.add.at(B, (np.arange(S * nsc), idx[c].astype(int)), w[c].astype(np.float64))
+    assert np.array_equal(inside, np.abs(w).sum(0) > 0)
+    assert np.max(np.abs(A - B)) < 2e-7                                  # float32 rounding of the stored host weights
+    tri = ip.triangulations_parallel([pil, pil], S, nsc, workers=2)
+    assert np.array_equal(tri[0], simp) and np.array_equal(tri[1], simp)
