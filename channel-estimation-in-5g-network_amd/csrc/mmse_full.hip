@@ -10,6 +10,7 @@
 //          interpolation.  This is the only MFMA-shaped work on the hot path.
 #include <stdlib.h>
 
+#include <stdio.h>
 #include "chest_device.h"
 #include "chest_internal.h"
 
@@ -70,15 +71,15 @@ __global__ void __launch_bounds__(256) gj_finish_kernel(int P, const cdd* __rest
 // ---- apply --------------------------------------------------------------------------------------
 // h_ls for every (frame, rx, tx) grid, stored [M][Ppad] (pilot index contiguous = GEMM K dimension).
 __global__ void __launch_bounds__(256)
-gather_ls_kernel(int S, int R, int T, int nsc, int P, int Ppad, const int32_t* __restrict__ pilot_idx,
+gather_ls_kernel(int S, int R, int T, int nsc, int P, int Ppad, int M, const int32_t* __restrict__ pilot_idx,
                  const float2* __restrict__ rx4d, const float2* __restrict__ tx_pilots, int pilot_stride,
                  float2* __restrict__ h) {
-    const int m = blockIdx.x;                       // (b*R + r)*T + t
+    const int m = blockIdx.x;                       // (b*R + r)*T + t; blocks beyond the last grid zero the tile padding
     const int t = m % T, r = (m / T) % R, b = m / (T * R);
     const size_t frame_base = (size_t)b * S * R * T * nsc;
     for (int i = threadIdx.x; i < Ppad; i += blockDim.x) {
         float2 v = make_float2(0.f, 0.f);
-        if (i < P) {
+        if (i < P && m < M) {
             const int g = pilot_idx[i];
             const int s = g / nsc, k = g - s * nsc;
             const float2 y = rx4d[frame_base + ((size_t)(s * R + r) * T + t) * nsc + k];
@@ -211,6 +212,98 @@ cgemm_w_kernel_v2(int P, int Ppad, int M, const float2* __restrict__ W, const fl
         }
 }
 
+// Third generation (default): same 128 x 128 block tile and 2 x 2 MFMA tiles per wave, but
+//   * both operands come from PACKED scratch copies -- rows padded to the tile, K padded to 16, zero filled -- so every
+//     thread fetches its 8 k-values of a row with four unconditional 16-B loads (v2: sixteen 8-B loads, each behind its own
+//     bounds branch: a 165-instruction stretch without a single MFMA per k-tile);
+//   * the LDS tiles are double buffered: the registers of tile t+1 are written to the other buffer right after the MFMA
+//     block of tile t, one barrier per k-tile instead of two.
+constexpr int T3_LD = T2_K + 1;
+constexpr size_t T3_LDS_BYTES = (size_t)2 * 2 * T2_M * T3_LD * sizeof(float2);      // 2 buffers x (A, B) = 69 632 B
+
+__global__ void __launch_bounds__(256)
+cgemm_w_kernel_v3(int P, int Kpad, int M, int ldo, const float2* __restrict__ Wp, const float2* __restrict__ Hin,
+                  float2* __restrict__ Hout) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    float2* const lds = (float2*)lds_raw;          // [buf][A | B][128][T3_LD]
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int i0 = blockIdx.x * T2_N, m0 = blockIdx.y * T2_M;
+    const int wm = (wave & 1) * 64, wi = (wave >> 1) * 64;
+    f32x16 cre[2][2], cim[2][2];
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { cre[x][y][e] = 0.f; cim[x][y][e] = 0.f; }
+    const int lrow = tid >> 1, lk = (tid & 1) * 8;
+    const float4* gh = (const float4*)(Hin + (size_t)(m0 + lrow) * Kpad + lk);      // 16-B aligned: Kpad % 16 == 0
+    const float4* gw = (const float4*)(Wp + (size_t)(i0 + lrow) * Kpad + lk);
+    float4 ph[4], pw[4];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { ph[q] = gh[(k0 >> 1) + q]; pw[q] = gw[(k0 >> 1) + q]; }
+    };
+    auto stage = [&](int buf) {
+        float2* Hs = lds + (size_t)buf * 2 * T2_M * T3_LD;
+        float2* Ws = Hs + T2_M * T3_LD;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            Hs[lrow * T3_LD + lk + 2 * q] = make_float2(ph[q].x, ph[q].y);
+            Hs[lrow * T3_LD + lk + 2 * q + 1] = make_float2(ph[q].z, ph[q].w);
+            Ws[lrow * T3_LD + lk + 2 * q] = make_float2(pw[q].x, pw[q].y);
+            Ws[lrow * T3_LD + lk + 2 * q + 1] = make_float2(pw[q].z, pw[q].w);
+        }
+    };
+    fetch(0);
+    stage(0);
+    __syncthreads();
+    const int nk = Kpad / T2_K;
+    for (int t = 0; t < nk; ++t) {
+        if (t + 1 < nk) fetch((t + 1) * T2_K);
+        const float2* Hs = lds + (size_t)(t & 1) * 2 * T2_M * T3_LD;
+        const float2* Ws = Hs + T2_M * T3_LD;
+#pragma unroll
+        for (int kk = 0; kk < T2_K; kk += 2) {
+            float2 a[2], b[2];
+#pragma unroll
+            for (int x = 0; x < 2; ++x) a[x] = Hs[(wm + 32 * x + (lane & 31)) * T3_LD + kk + (lane >> 5)];
+#pragma unroll
+            for (int y = 0; y < 2; ++y) b[y] = Ws[(wi + 32 * y + (lane & 31)) * T3_LD + kk + (lane >> 5)];
+#pragma unroll
+            for (int x = 0; x < 2; ++x)
+#pragma unroll
+                for (int y = 0; y < 2; ++y) {
+                    cre[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[x].x, b[y].x, cre[x][y], 0, 0, 0);
+                    cre[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(-a[x].y, b[y].y, cre[x][y], 0, 0, 0);
+                    cim[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[x].x, b[y].y, cim[x][y], 0, 0, 0);
+                    cim[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[x].y, b[y].x, cim[x][y], 0, 0, 0);
+                }
+        }
+        if (t + 1 < nk) stage((t + 1) & 1);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y) {
+            const int i = i0 + wi + 32 * y + (lane & 31);
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int m = m0 + wm + 32 * x + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+                if (m < M && i < P) Hout[(size_t)m * ldo + i] = make_float2(cre[x][y][reg], cim[x][y][reg]);
+            }
+        }
+}
+
+// W [P][P] -> Wp [Npad][Kpad], zero padded (Npad = P rounded up to the 128-row block tile, Kpad = P rounded up to 16)
+__global__ void __launch_bounds__(256)
+pack_w_kernel(int P, int Kpad, const float2* __restrict__ W, float2* __restrict__ Wp) {
+    const int i = blockIdx.x;
+    for (int k = threadIdx.x; k < Kpad; k += blockDim.x)
+        Wp[(size_t)i * Kpad + k] = (i < P && k < P) ? W[(size_t)i * P + k] : make_float2(0.f, 0.f);
+}
+
 // plan-driven interpolation of precomputed pilot values h[m][Ppad] (same arithmetic as estimate_kernel)
 __global__ void __launch_bounds__(256)
 interp_from_pilots_kernel(int S, int R, int T, int nsc, int Ppad, const PatternDev* __restrict__ patterns, int slot,
@@ -277,6 +370,7 @@ dense_interp_kernel(int S, int R, int T, int nsc, int P, int Ppad, int M, const 
 }
 
 static inline int pad16(int p) { return (p + 15) & ~15; }
+static inline int pad128(int p) { return (p + 127) & ~127; }
 
 }  // namespace chest
 
@@ -314,6 +408,12 @@ int chest_mmse_full_prepare(chest_ctx* ctx, void* stream, int32_t P, const doubl
     return CHEST_OK;
 }
 
+int64_t chest_mmse_full_apply_scratch_bytes(int32_t P, int32_t num_grids) {
+    if (P <= 0 || num_grids <= 0) return 0;
+    const int64_t Ppad = pad16(P);
+    return (int64_t)sizeof(float2) * Ppad * ((int64_t)pad128(num_grids) + num_grids + pad128(P));
+}
+
 int chest_mmse_full_apply(chest_ctx* ctx, void* stream, int32_t B, const float* rx4d, const float* tx_pilots,
                           int32_t pilot_stride, int32_t slot, const float* W, float* h_scratch, float* H_est) {
     if (!ctx || B < 0 || (B > 0 && (!rx4d || !tx_pilots || !W || !h_scratch || !H_est))) {
@@ -330,16 +430,26 @@ int chest_mmse_full_apply(chest_ctx* ctx, void* stream, int32_t B, const float* 
     const auto& f = ctx->fp;
     const PatternDev& pd = ctx->patterns[slot].dev;
     const int P = pd.P, Ppad = pad16(P), M = B * f.R * f.T;
+    // scratch layout (chest_mmse_full_apply_scratch_bytes): h_in [Mpad][Ppad] | h_out [M][Ppad] | Wp [Npad][Ppad]
+    const int Mpad = pad128(M), Npad = pad128(P);
     float2* h_in = (float2*)h_scratch;
-    float2* h_out = h_in + (size_t)M * Ppad;
-    hipLaunchKernelGGL(gather_ls_kernel, dim3(M), dim3(256), 0, st, f.S, f.R, f.T, f.nsc, P, Ppad, pd.pilot_idx,
+    float2* h_out = h_in + (size_t)Mpad * Ppad;
+    float2* w_packed = h_out + (size_t)M * Ppad;
+    hipLaunchKernelGGL(gather_ls_kernel, dim3(Mpad), dim3(256), 0, st, f.S, f.R, f.T, f.nsc, P, Ppad, M, pd.pilot_idx,
                        (const float2*)rx4d, (const float2*)tx_pilots, pilot_stride, h_in);
-    if (getenv("CHEST_GEMM_V1"))          // A/B switch for the first-generation 64x64 tile
+    const char* gv = getenv("CHEST_GEMM");   // A/B switch: "1" = first 64x64 tile, "2" = 128x128 with register prefetch
+    if (gv && gv[0] == '1')
         hipLaunchKernelGGL(cgemm_w_kernel, dim3((P + GB_M - 1) / GB_M, (M + GB_N - 1) / GB_N), dim3(256), 0, st, P, Ppad, M,
                            (const float2*)W, h_in, h_out);
-    else
+    else if (gv && gv[0] == '2')
         hipLaunchKernelGGL(cgemm_w_kernel_v2, dim3((P + T2_N - 1) / T2_N, (M + T2_M - 1) / T2_M), dim3(256), 0, st, P, Ppad, M,
                            (const float2*)W, h_in, h_out);
+    else {
+        hipLaunchKernelGGL(pack_w_kernel, dim3(Npad), dim3(256), 0, st, P, Ppad, (const float2*)W, w_packed);
+        CHEST_LDS_OPT_IN(ctx, LDS_GEMM, cgemm_w_kernel_v3, T3_LDS_BYTES);
+        hipLaunchKernelGGL(cgemm_w_kernel_v3, dim3(Npad / T2_N, Mpad / T2_M), dim3(256), T3_LDS_BYTES, st, P, Ppad, M, Ppad,
+                           (const float2*)w_packed, h_in, h_out);
+    }
     const size_t lds = (size_t)P * sizeof(float2);
     CHEST_LDS_OPT_IN(ctx, LDS_INTERP, interp_from_pilots_kernel, lds);
     hipLaunchKernelGGL(interp_from_pilots_kernel, dim3(M), dim3(256), lds, st, f.S, f.R, f.T, f.nsc, Ppad, ctx->d_patterns,
@@ -363,7 +473,7 @@ int chest_estimate_dense(chest_ctx* ctx, void* stream, int32_t B, const float* r
     const auto& f = ctx->fp;
     const PatternDev& pd = ctx->patterns[slot].dev;
     const int P = pd.P, Ppad = pad16(P), M = B * f.R * f.T;
-    hipLaunchKernelGGL(gather_ls_kernel, dim3(M), dim3(256), 0, st, f.S, f.R, f.T, f.nsc, P, Ppad, pd.pilot_idx,
+    hipLaunchKernelGGL(gather_ls_kernel, dim3(M), dim3(256), 0, st, f.S, f.R, f.T, f.nsc, P, Ppad, M, pd.pilot_idx,
                        (const float2*)rx4d, (const float2*)tx_pilots, pilot_stride, (float2*)h_scratch);
     hipLaunchKernelGGL(dense_interp_kernel, dim3((f.G + GB_N - 1) / GB_N, (M + GB_M - 1) / GB_M), dim3(256), 0, st, f.S, f.R,
                        f.T, f.nsc, P, Ppad, M, A, (const float2*)h_scratch, (float2*)H_est);

@@ -243,9 +243,12 @@ int chest_bit_errors(chest_ctx* ctx, void* stream, int64_t n, const uint8_t* a, 
 int chest_mmse_full_prepare(chest_ctx* ctx, void* stream, int32_t num_pilots, const double* cov,
                             float snr_db, float* W, double* workspace, int64_t workspace_bytes);
 int64_t chest_mmse_full_workspace_bytes(int32_t num_pilots);
+/* DEVICE scratch chest_mmse_full_apply needs for num_grids = B*R*T right-hand sides (gathered h_ls and W repacked
+ * to the GEMM's tile padding, plus the product). */
+int64_t chest_mmse_full_apply_scratch_bytes(int32_t num_pilots, int32_t num_grids);
 int chest_mmse_full_apply(chest_ctx* ctx, void* stream, int32_t num_frames, const float* rx4d,
                           const float* tx_pilots, int32_t pilot_stride, int32_t pattern_slot,
-                          const float* W, float* h_scratch /*[2][B*R*T][roundup16(P)] c64*/, float* H_est);
+                          const float* W, float* h_scratch /* chest_mmse_full_apply_scratch_bytes(P, B*R*T) */, float* H_est);
 
 /* LSEstimator('cubic').estimate (src/baseline_estimators.py:65-79 with method='cubic' = scipy Clough-Tocher): the
  * interpolation is a dense linear operator A [G][P] float32 (DEVICE; built on the host once per pattern from scipy's own

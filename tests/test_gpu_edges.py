@@ -165,3 +165,46 @@ def test_device_built_linear_plan_equals_scipy_plan(fft, cp, U, P, seed):
     assert relerr(a, b) < 1e-6
     with pytest.raises(Exception):
         eng.set_pattern(2, pil, np.array([[0, 1, P]], dtype=np.int32))               # vertex outside 0..P-1
+
+
+def _config5_covariance(N, cp, U, T, ct, fd, pil, S=14):
+    """R[(s,k),(s',k')] = T * sum_l p_l e^{-2 pi j (kappa_k - kappa_k') d_l / N} * J0(2 pi f_d (t_s - t_s'))."""
+    from scipy.special import j0
+    nsc = len(O.used_indices(N, U)); fs = N * 15000.0
+    p, d = O.tap_table(ct, fs); kap = O.used_indices(N, U) - N // 2
+    ps, pk = np.unravel_index(pil, (S, nsc))
+    dk = kap[pk][:, None] - kap[pk][None, :]
+    Rf = sum(pl * np.exp(-2j * np.pi * dk * dl / N) for pl, dl in zip(p, d))
+    ts = ps * (N + cp) / fs
+    return T * Rf * j0(2 * np.pi * fd * (ts[:, None] - ts[None, :]))
+
+
+@pytest.mark.parametrize("N,cp,U,T,R,B", [(2048, 144, 1200, 4, 4, 3), (1024, 72, 600, 2, 2, 37)])
+def test_full_covariance_mmse_at_baseline_sizes(N, cp, U, T, R, B):
+    """MMSEEstimator(channel_covariance=R, estimate_statistics=False) at the BASELINE config-5 size (P = 1 678, 4x4,
+    2048-FFT) and at P = 838: device float64 prepare against NumPy's inverse, and the MFMA apply (packed operands; the
+    number of grids is not a multiple of the 128-row tile) against float64 W @ h_ls + the oracle's linear interpolation."""
+    geom = E.Geometry(fft_size=N, cp_length=cp, useful_subcarriers=U, num_tx=T, num_rx=R)
+    eng = E.get_engine(geom, 0)
+    S, nsc, G = geom.num_symbols, geom.num_sc, geom.grid
+    P = int(G * 0.1)
+    pil = np.sort(np.random.RandomState(21).permutation(G)[:P])
+    slot = eng.pattern_slot(pil, "linear")
+    cov = _config5_covariance(N, cp, U, T, "ETU", 555.6, pil)
+    snr = 10.0
+    W = eng.mmse_full_prepare(cov, snr)
+    Wref = cov @ np.linalg.inv(cov + 10 ** (-snr / 10) * np.eye(P))
+    assert relerr(W.cpu().numpy(), Wref) < 1e-6
+    sim = eng.run_frames(E.make_descs("ETU", 555.6, snr, slot, n=B), seed=9, outputs=("rx", "pilot_symbols"))
+    rx4 = sim["rx"][:, :, :, None, :].expand(B, S, R, T, nsc).contiguous()
+    xp = sim["pilot_symbols"][:, :P].contiguous()
+    got = eng.mmse_full_apply(rx4, xp, slot, W).cpu().numpy()
+    rx_h, xp_h = sim["rx"].cpu().numpy().astype(np.complex128), xp.cpu().numpy().astype(np.complex128)
+    ps, pk = np.unravel_index(pil, (S, nsc))
+    mask, pos = O.pattern_from_indices(pil, S, nsc)[1], O.pattern_from_indices(pil, S, nsc)[0]
+    for b in (0, B - 1):
+        for r in (0, R - 1):
+            h_ls = rx_h[b, :, r, :][mask] / (xp_h[b] + 1e-12)
+            want = O._griddata_complex(Wref @ h_ls, pos, (S, nsc), "linear")
+            for t in (0, T - 1):
+                assert relerr(got[b, :, r, t, :], want) < TOL

@@ -18,7 +18,14 @@ def covariance(N, cp, U, T, ct, fd, pil, S=14):
     ts = ps * (N + cp) / fs
     return T * Rf * j0(2 * np.pi * fd * (ts[:, None] - ts[None, :]))
 
-for (N, cp, U, T, R, B) in ((1024, 72, 600, 2, 2, 2048), (2048, 144, 1200, 4, 4, 512)):
+import argparse
+_ap = argparse.ArgumentParser()
+_ap.add_argument("--only-big", action="store_true", help="only the config-5 shape")
+_ap.add_argument("--frames", type=int, default=0, help="frames per apply for the config-5 shape (default 512)")
+_ap.add_argument("--no-rocblas", action="store_true")
+_args = _ap.parse_args()
+_cases = ((1024, 72, 600, 2, 2, 2048), (2048, 144, 1200, 4, 4, _args.frames or 512))
+for (N, cp, U, T, R, B) in (_cases[1:] if _args.only_big else _cases):
     geom = E.Geometry(fft_size=N, cp_length=cp, useful_subcarriers=U, num_tx=T, num_rx=R)
     eng = E.Engine(geom, 0)
     G = geom.grid; P = int(G * 0.1)
@@ -46,4 +53,22 @@ for (N, cp, U, T, R, B) in ((1024, 72, 600, 2, 2, 2048), (2048, 144, 1200, 4, 4,
     flops = 8.0 * P * P * B * R * T
     print(f"{T}x{R} N={N} P={P}: prepare {t_prep*1e3:8.1f} ms (W rel err {err:.1e});  apply {B} frames {ms:8.2f} ms = "
           f"{B / ms * 1e3:9.0f} frames/s, {flops / ms * 1e-9:6.1f} TFLOP/s of 157.3 (whole apply: gather + GEMM + interpolation)", flush=True)
+    # comparator (not the product): rocBLAS through torch on the same shapes -- complex64 cgemm W @ X and a float32
+    # sgemm with the same real flop count -- to see what the library sustains on this box
+    if _args.no_rocblas:
+        del eng
+        continue
+    Mcols = B * R * T
+    X = torch.randn(P, Mcols, dtype=torch.complex64, device="cuda")
+    Wt = W.contiguous()
+    A32 = torch.randn(2 * P, 2 * P, device="cuda"); X32 = torch.randn(2 * P, Mcols, device="cuda")
+    for name, fn, fl in (("rocBLAS cgemm", lambda: torch.matmul(Wt, X), 8.0 * P * P * Mcols),
+                         ("rocBLAS sgemm (2P x 2P real form)", lambda: torch.matmul(A32, X32), 2.0 * 4 * P * P * Mcols)):
+        fn(); torch.cuda.synchronize()
+        a.record()
+        for _ in range(5):
+            fn()
+        b.record(); torch.cuda.synchronize()
+        ms2 = a.elapsed_time(b) / 5
+        print(f"      {name}: {ms2:7.2f} ms = {fl / ms2 * 1e-9:6.1f} TFLOP/s", flush=True)
     del eng
