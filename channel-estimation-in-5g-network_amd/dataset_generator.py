@@ -142,13 +142,18 @@ class ChannelEstimationDataset:
             b1 = min(n, b0 + batch_frames)
             descs = _engine.make_descs(ctype[b0:b1], fd[b0:b1], snr[b0:b1], slots[b0:b1], n=b1 - b0)
             out = eng.run_frames(descs, seed=seed, frame_offset=int(begin + b0), outputs=names)
+            out["pilot_mask"] = out["pilot_mask"].to(torch.float32)           # reference schema: f32 mask; converted on the device
             for k in names:
-                chunks[k].append(out[k].cpu() if to_numpy else out[k])
-        cat = {k: (torch.cat(v) if v else torch.empty(0)) for k, v in chunks.items()}
-        conv = (lambda t: t.numpy()) if to_numpy else (lambda t: t)
+                chunks[k].append(out[k].cpu().numpy() if to_numpy else out[k])
+        # host side stays in NumPy: CPU-tensor ops would start torch's intra-op thread pool (see engine._dev)
+        if to_numpy:
+            cat = {k: (np.concatenate(v) if v else np.empty(0)) for k, v in chunks.items()}
+        else:
+            cat = {k: (torch.cat(v) if v else torch.empty(0)) for k, v in chunks.items()}
+        conv = lambda t: t
         rec = {
             'rx_symbols': conv(cat["rx"]), 'tx_symbols': conv(cat["tx"]), 'H_ls': conv(cat["H_ls"]),
-            'H_true': conv(cat["H"]), 'pilot_mask': conv(cat["pilot_mask"].to(torch.float32)),
+            'H_true': conv(cat["H"]), 'pilot_mask': conv(cat["pilot_mask"]),
             'snr_db': snr.astype(np.float32), 'channel_type': np.asarray(CHANNEL_NAMES)[ctype].astype('U3'),
             'doppler_hz': fd.astype(np.float32), 'pilot_density': dens.astype(np.float32),
             'frame_index': idx, 'metrics': conv(cat["metrics"]),
