@@ -69,7 +69,7 @@ struct chest_ctx {
     chest::FrameParams* d_fp = nullptr;   // device copy of fp (kernels read it through uniform scalar loads)
     std::vector<void*> prof_events;       // hipEvent_t triples (before taps, before frame kernel, after) when profiling
     int32_t prof_used = 0;                // triples recorded since chest_profile_begin
-    size_t lds_opt_in[5] = {0, 0, 0, 0, 0};   // largest dynamic-LDS size already opted in per kernel (per context = per device)
+    size_t lds_opt_in[6] = {0, 0, 0, 0, 0, 0};   // largest dynamic-LDS size already opted in per kernel (per context = per device)
 };
 
 namespace chest {
@@ -84,7 +84,7 @@ void set_error(const char* fmt, ...);
         }                                                                            \
     } while (0)
 
-enum { LDS_TAPS = 0, LDS_FRAME = 1, LDS_ESTIMATE = 2, LDS_INTERP = 3, LDS_GEMM = 4 };
+enum { LDS_TAPS = 0, LDS_FRAME = 1, LDS_ESTIMATE = 2, LDS_INTERP = 3, LDS_GEMM = 4, LDS_GEMM3M = 5 };
 // kernels that use more than 64 KiB of dynamic LDS must opt in once per device; cached in the context
 #define CHEST_LDS_OPT_IN(ctx, which, fn, bytes)                                                                    \
     do {                                                                                                       \

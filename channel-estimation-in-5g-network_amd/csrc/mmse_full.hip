@@ -296,6 +296,91 @@ cgemm_w_kernel_v3(int P, int Kpad, int M, int ldo, const float2* __restrict__ Wp
         }
 }
 
+// Three-multiplication complex product ("3M"): (ar + j ai)(br + j bi) = (ar br - ai bi) + j((ar + ai)(br + bi) - ar br - ai bi),
+// i.e. three real MFMAs per complex k-pair instead of four (-25 % matrix work) for three accumulator sets instead of two
+// (192 AGPRs).  Rounding: measured 1.05e-6 of max|W h| against float64 at P = 1 678 (four-multiplication form: 7.8e-7).
+__global__ void __launch_bounds__(256, 2)
+cgemm_w_kernel_3m(int P, int Kpad, int M, int ldo, const float2* __restrict__ Wp, const float2* __restrict__ Hin,
+                  float2* __restrict__ Hout) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    float2* const lds = (float2*)lds_raw;          // [buf][A | B][128][T3_LD]
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int i0 = blockIdx.x * T2_N, m0 = blockIdx.y * T2_M;
+    const int wm = (wave & 1) * 64, wi = (wave >> 1) * 64;
+    f32x16 t1[2][2], t2[2][2], t3[2][2];          // sum ar*br, sum ai*bi, sum (ar+ai)*(br+bi)
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { t1[x][y][e] = 0.f; t2[x][y][e] = 0.f; t3[x][y][e] = 0.f; }
+    const int lrow = tid >> 1, lk = (tid & 1) * 8;
+    const float4* gh = (const float4*)(Hin + (size_t)(m0 + lrow) * Kpad + lk);      // 16-B aligned: Kpad % 16 == 0
+    const float4* gw = (const float4*)(Wp + (size_t)(i0 + lrow) * Kpad + lk);
+    float4 ph[4], pw[4];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { ph[q] = gh[(k0 >> 1) + q]; pw[q] = gw[(k0 >> 1) + q]; }
+    };
+    auto stage = [&](int buf) {
+        float2* Hs = lds + (size_t)buf * 2 * T2_M * T3_LD;
+        float2* Ws = Hs + T2_M * T3_LD;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            Hs[lrow * T3_LD + lk + 2 * q] = make_float2(ph[q].x, ph[q].y);
+            Hs[lrow * T3_LD + lk + 2 * q + 1] = make_float2(ph[q].z, ph[q].w);
+            Ws[lrow * T3_LD + lk + 2 * q] = make_float2(pw[q].x, pw[q].y);
+            Ws[lrow * T3_LD + lk + 2 * q + 1] = make_float2(pw[q].z, pw[q].w);
+        }
+    };
+    fetch(0);
+    stage(0);
+    __syncthreads();
+    const int nk = Kpad / T2_K;
+    for (int t = 0; t < nk; ++t) {
+        if (t + 1 < nk) fetch((t + 1) * T2_K);
+        const float2* Hs = lds + (size_t)(t & 1) * 2 * T2_M * T3_LD;
+        const float2* Ws = Hs + T2_M * T3_LD;
+#pragma unroll
+        for (int kk = 0; kk < T2_K; kk += 2) {
+            float2 a[2], b[2];
+#pragma unroll
+            for (int x = 0; x < 2; ++x) a[x] = Hs[(wm + 32 * x + (lane & 31)) * T3_LD + kk + (lane >> 5)];
+#pragma unroll
+            for (int y = 0; y < 2; ++y) b[y] = Ws[(wi + 32 * y + (lane & 31)) * T3_LD + kk + (lane >> 5)];
+            float as[2], bs[2];
+#pragma unroll
+            for (int x = 0; x < 2; ++x) as[x] = a[x].x + a[x].y;
+#pragma unroll
+            for (int y = 0; y < 2; ++y) bs[y] = b[y].x + b[y].y;
+#pragma unroll
+            for (int x = 0; x < 2; ++x)
+#pragma unroll
+                for (int y = 0; y < 2; ++y) {
+                    t1[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[x].x, b[y].x, t1[x][y], 0, 0, 0);
+                    t2[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[x].y, b[y].y, t2[x][y], 0, 0, 0);
+                    t3[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(as[x], bs[y], t3[x][y], 0, 0, 0);
+                }
+        }
+        if (t + 1 < nk) stage((t + 1) & 1);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y) {
+            const int i = i0 + wi + 32 * y + (lane & 31);
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int m = m0 + wm + 32 * x + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+                if (m < M && i < P) {
+                    const float p1 = t1[x][y][reg], p2 = t2[x][y][reg];
+                    Hout[(size_t)m * ldo + i] = make_float2(p1 - p2, t3[x][y][reg] - p1 - p2);
+                }
+            }
+        }
+}
+
 // W [P][P] -> Wp [Npad][Kpad], zero padded (Npad = P rounded up to the 128-row block tile, Kpad = P rounded up to 16)
 __global__ void __launch_bounds__(256)
 pack_w_kernel(int P, int Kpad, const float2* __restrict__ W, float2* __restrict__ Wp) {
@@ -446,9 +531,15 @@ int chest_mmse_full_apply(chest_ctx* ctx, void* stream, int32_t B, const float* 
                            (const float2*)W, h_in, h_out);
     else {
         hipLaunchKernelGGL(pack_w_kernel, dim3(Npad), dim3(256), 0, st, P, Ppad, (const float2*)W, w_packed);
-        CHEST_LDS_OPT_IN(ctx, LDS_GEMM, cgemm_w_kernel_v3, T3_LDS_BYTES);
-        hipLaunchKernelGGL(cgemm_w_kernel_v3, dim3(Npad / T2_N, Mpad / T2_M), dim3(256), T3_LDS_BYTES, st, P, Ppad, M, Ppad,
-                           (const float2*)w_packed, h_in, h_out);
+        if (gv && gv[0] == '3') {         // four real MFMAs per complex k-pair
+            CHEST_LDS_OPT_IN(ctx, LDS_GEMM, cgemm_w_kernel_v3, T3_LDS_BYTES);
+            hipLaunchKernelGGL(cgemm_w_kernel_v3, dim3(Npad / T2_N, Mpad / T2_M), dim3(256), T3_LDS_BYTES, st, P, Ppad, M, Ppad,
+                               (const float2*)w_packed, h_in, h_out);
+        } else {                          // default: three
+            CHEST_LDS_OPT_IN(ctx, LDS_GEMM3M, cgemm_w_kernel_3m, T3_LDS_BYTES);
+            hipLaunchKernelGGL(cgemm_w_kernel_3m, dim3(Npad / T2_N, Mpad / T2_M), dim3(256), T3_LDS_BYTES, st, P, Ppad, M, Ppad,
+                               (const float2*)w_packed, h_in, h_out);
+        }
     }
     const size_t lds = (size_t)P * sizeof(float2);
     CHEST_LDS_OPT_IN(ctx, LDS_INTERP, interp_from_pilots_kernel, lds);
