@@ -454,6 +454,104 @@ dense_interp_kernel(int S, int R, int T, int nsc, int P, int Ppad, int M, const 
     }
 }
 
+// Second generation of the dense ('cubic') interpolation GEMM, built like cgemm_w_kernel_v3: 128 (grids m) x 128
+// (resource elements g) block tile, 2 x 2 MFMA tiles per wave, operands from tile-padded scratch copies through 16-B loads,
+// double-buffered LDS, one barrier per k-tile.  A is real: two MFMAs per k-pair and sub-tile.
+constexpr int D2_LDH = T2_K + 1, D2_LDA = T2_K + 1;
+constexpr size_t D2_LDS_BYTES = (size_t)2 * (T2_M * D2_LDH * sizeof(float2) + T2_N * D2_LDA * sizeof(float));   // 52 224 B
+
+__global__ void __launch_bounds__(256, 2)
+dense_interp_kernel_v2(int S, int R, int T, int nsc, int Kpad, int M, const float* __restrict__ Ap,
+                       const float2* __restrict__ Hin, float2* __restrict__ H_est) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    constexpr size_t BUF = T2_M * D2_LDH * sizeof(float2) + T2_N * D2_LDA * sizeof(float);
+    const int G = S * nsc;
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int g0 = blockIdx.x * T2_N, m0 = blockIdx.y * T2_M;
+    const int wm = (wave & 1) * 64, wg = (wave >> 1) * 64;
+    f32x16 cre[2][2], cim[2][2];
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { cre[x][y][e] = 0.f; cim[x][y][e] = 0.f; }
+    const int lrow = tid >> 1, lk = (tid & 1) * 8;
+    const float4* gh = (const float4*)(Hin + (size_t)(m0 + lrow) * Kpad + lk);      // 8 float2 = 4 x 16 B
+    const float4* ga = (const float4*)(Ap + (size_t)(g0 + lrow) * Kpad + lk);       // 8 float  = 2 x 16 B
+    float4 ph[4], pa[2];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) ph[q] = gh[(k0 >> 1) + q];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) pa[q] = ga[(k0 >> 2) + q];
+    };
+    auto stage = [&](int buf) {
+        float2* Hs = (float2*)(lds_raw + (size_t)buf * BUF);
+        float* As = (float*)(Hs + T2_M * D2_LDH);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            Hs[lrow * D2_LDH + lk + 2 * q] = make_float2(ph[q].x, ph[q].y);
+            Hs[lrow * D2_LDH + lk + 2 * q + 1] = make_float2(ph[q].z, ph[q].w);
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            As[lrow * D2_LDA + lk + 4 * q] = pa[q].x; As[lrow * D2_LDA + lk + 4 * q + 1] = pa[q].y;
+            As[lrow * D2_LDA + lk + 4 * q + 2] = pa[q].z; As[lrow * D2_LDA + lk + 4 * q + 3] = pa[q].w;
+        }
+    };
+    fetch(0);
+    stage(0);
+    __syncthreads();
+    const int nk = Kpad / T2_K;
+    for (int t = 0; t < nk; ++t) {
+        if (t + 1 < nk) fetch((t + 1) * T2_K);
+        const float2* Hs = (const float2*)(lds_raw + (size_t)(t & 1) * BUF);
+        const float* As = (const float*)(Hs + T2_M * D2_LDH);
+#pragma unroll
+        for (int kk = 0; kk < T2_K; kk += 2) {
+            float2 a[2];
+            float b[2];
+#pragma unroll
+            for (int x = 0; x < 2; ++x) a[x] = Hs[(wm + 32 * x + (lane & 31)) * D2_LDH + kk + (lane >> 5)];
+#pragma unroll
+            for (int y = 0; y < 2; ++y) b[y] = As[(wg + 32 * y + (lane & 31)) * D2_LDA + kk + (lane >> 5)];
+#pragma unroll
+            for (int x = 0; x < 2; ++x)
+#pragma unroll
+                for (int y = 0; y < 2; ++y) {
+                    cre[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[x].x, b[y], cre[x][y], 0, 0, 0);
+                    cim[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[x].y, b[y], cim[x][y], 0, 0, 0);
+                }
+        }
+        if (t + 1 < nk) stage((t + 1) & 1);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int y = 0; y < 2; ++y) {
+        const int g = g0 + wg + 32 * y + (lane & 31);
+        if (g >= G) continue;
+        const int s = g / nsc, k = g - s * nsc;
+#pragma unroll
+        for (int x = 0; x < 2; ++x)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int m = m0 + wm + 32 * x + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+                if (m < M) {
+                    const int t = m % T, r = (m / T) % R, b = m / (T * R);
+                    H_est[(((size_t)b * S + s) * R + r) * T * nsc + (size_t)t * nsc + k] = make_float2(cre[x][y][reg], cim[x][y][reg]);
+                }
+            }
+    }
+}
+
+// A [G][P] -> Ap [Gpad][Kpad] float, zero padded
+__global__ void __launch_bounds__(256)
+pack_a_kernel(int G, int P, int Kpad, const float* __restrict__ A, float* __restrict__ Ap) {
+    const int g = blockIdx.x;
+    for (int k = threadIdx.x; k < Kpad; k += blockDim.x) Ap[(size_t)g * Kpad + k] = (g < G && k < P) ? A[(size_t)g * P + k] : 0.f;
+}
+
 static inline int pad16(int p) { return (p + 15) & ~15; }
 static inline int pad128(int p) { return (p + 127) & ~127; }
 
@@ -549,6 +647,12 @@ int chest_mmse_full_apply(chest_ctx* ctx, void* stream, int32_t B, const float* 
     return CHEST_OK;
 }
 
+int64_t chest_estimate_dense_scratch_bytes(chest_ctx* ctx, int32_t P, int32_t num_grids) {
+    if (!ctx || P <= 0 || num_grids <= 0) return 0;
+    const int64_t Ppad = pad16(P);
+    return Ppad * ((int64_t)sizeof(float2) * pad128(num_grids) + (int64_t)sizeof(float) * pad128(ctx->fp.G));
+}
+
 int chest_estimate_dense(chest_ctx* ctx, void* stream, int32_t B, const float* rx4d, const float* tx_pilots,
                          int32_t pilot_stride, int32_t slot, const float* A, float* h_scratch, float* H_est) {
     if (!ctx || B < 0 || (B > 0 && (!rx4d || !tx_pilots || !A || !h_scratch || !H_est))) {
@@ -564,10 +668,23 @@ int chest_estimate_dense(chest_ctx* ctx, void* stream, int32_t B, const float* r
     const auto& f = ctx->fp;
     const PatternDev& pd = ctx->patterns[slot].dev;
     const int P = pd.P, Ppad = pad16(P), M = B * f.R * f.T;
-    hipLaunchKernelGGL(gather_ls_kernel, dim3(M), dim3(256), 0, st, f.S, f.R, f.T, f.nsc, P, Ppad, M, pd.pilot_idx,
-                       (const float2*)rx4d, (const float2*)tx_pilots, pilot_stride, (float2*)h_scratch);
-    hipLaunchKernelGGL(dense_interp_kernel, dim3((f.G + GB_N - 1) / GB_N, (M + GB_M - 1) / GB_M), dim3(256), 0, st, f.S, f.R,
-                       f.T, f.nsc, P, Ppad, M, A, (const float2*)h_scratch, (float2*)H_est);
+    // scratch layout (chest_estimate_dense_scratch_bytes): h [Mpad][Ppad] c64 | Ap [Gpad][Ppad] f32
+    const int Mpad = pad128(M), Gpad = pad128(f.G);
+    float2* h_in = (float2*)h_scratch;
+    float* a_packed = (float*)(h_in + (size_t)Mpad * Ppad);
+    const char* gv = getenv("CHEST_DENSE");      // A/B switch: "1" = first-generation 64x64 tile reading A in place
+    if (gv && gv[0] == '1') {
+        hipLaunchKernelGGL(gather_ls_kernel, dim3(M), dim3(256), 0, st, f.S, f.R, f.T, f.nsc, P, Ppad, M, pd.pilot_idx,
+                           (const float2*)rx4d, (const float2*)tx_pilots, pilot_stride, h_in);
+        hipLaunchKernelGGL(dense_interp_kernel, dim3((f.G + GB_N - 1) / GB_N, (M + GB_M - 1) / GB_M), dim3(256), 0, st, f.S, f.R,
+                           f.T, f.nsc, P, Ppad, M, A, (const float2*)h_in, (float2*)H_est);
+    } else {
+        hipLaunchKernelGGL(gather_ls_kernel, dim3(Mpad), dim3(256), 0, st, f.S, f.R, f.T, f.nsc, P, Ppad, M, pd.pilot_idx,
+                           (const float2*)rx4d, (const float2*)tx_pilots, pilot_stride, h_in);
+        hipLaunchKernelGGL(pack_a_kernel, dim3(Gpad), dim3(256), 0, st, f.G, P, Ppad, A, a_packed);
+        hipLaunchKernelGGL(dense_interp_kernel_v2, dim3(Gpad / T2_N, Mpad / T2_M), dim3(256), D2_LDS_BYTES, st, f.S, f.R, f.T,
+                           f.nsc, Ppad, M, (const float*)a_packed, (const float2*)h_in, (float2*)H_est);
+    }
     CHEST_HIP(hipGetLastError());
     return CHEST_OK;
 }

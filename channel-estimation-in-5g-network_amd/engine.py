@@ -384,7 +384,7 @@ class Engine:
         if tp.numel() != (P if tp.dim() == 1 else B * P):
             raise ValueError("tx_pilots does not match the pattern's pilot count")
         M = B * g.num_rx * g.num_tx
-        scratch = self.empty_c64(M, (P + 15) // 16 * 16)
+        scratch = torch.empty(N.lib().chest_estimate_dense_scratch_bytes(self._h, P, M), dtype=torch.uint8, device=self.device)
         out = torch.empty_like(rx)
         N.check(N.lib().chest_estimate_dense(self._h, self._stream(), B, rx.data_ptr(), tp.data_ptr(), stride, int(slot),
                                              A.contiguous().data_ptr(), scratch.data_ptr(), out.data_ptr()),

@@ -253,7 +253,9 @@ int chest_mmse_full_apply(chest_ctx* ctx, void* stream, int32_t num_frames, cons
 /* LSEstimator('cubic').estimate (src/baseline_estimators.py:65-79 with method='cubic' = scipy Clough-Tocher): the
  * interpolation is a dense linear operator A [G][P] float32 (DEVICE; built on the host once per pattern from scipy's own
  * interpolator, see interp_plan.cubic_operator), applied to the LS pilot estimates of all B*R*T grids as a real x complex
- * GEMM on the f32 MFMA pipe.  h_scratch: DEVICE [B*R*T][roundup16(P)] c64. */
+ * GEMM on the f32 MFMA pipe.  h_scratch: DEVICE, chest_estimate_dense_scratch_bytes(ctx, P, B*R*T) bytes (gathered h_ls and
+ * A repacked to the GEMM's tile padding). */
+int64_t chest_estimate_dense_scratch_bytes(chest_ctx* ctx, int32_t num_pilots, int32_t num_grids);
 int chest_estimate_dense(chest_ctx* ctx, void* stream, int32_t num_frames, const float* rx4d, const float* tx_pilots,
                          int32_t pilot_stride, int32_t pattern_slot, const float* A, float* h_scratch, float* H_est);
 
