@@ -108,6 +108,8 @@ def main():
                     help="frames sharing one pilot pattern + interpolation plan; 1 = a new random pattern per frame as the "
                          "reference draws them (Qhull triangulation on the host, plan on the device, BEFORE the timed region)")
     ap.add_argument("--plan-workers", type=int, default=0, help="host processes for plan building (0 = min(16, cores))")
+    ap.add_argument("--placement-tries", type=int, default=4,
+                    help="candidate allocations per output tensor group; the fastest placement is kept (1 = take the first)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--with-metrics", action="store_true", help="also produce the fused error sums inside the timed step")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
@@ -168,7 +170,9 @@ def main():
     names = ["tx", "rx", "H", "H_ls", "H_mmse", "pilot_symbols", "pilot_mask"]
     if args.with_metrics:
         names.append("metrics")
-    out = eng.run_frames(d_dev, seed=2024, frame_offset=0, outputs=names)       # allocates + first launch
+    # Output buffers are allocated once and reused by every step.  Where they live matters on MI355X (Engine.place_outputs,
+    # DESIGN.md section 5): probe a few placements per tensor group with the real kernel and keep the fastest.
+    out, placement = eng.place_outputs(d_dev, names, seed=2024, tries=args.placement_tries)
     torch.cuda.synchronize()
 
     def step(i):
@@ -234,6 +238,7 @@ def main():
                        "channel": ct, "doppler_hz": fd, "snr_db": snr, "pilot_density": dens, "pilots": P,
                        "estimators": "LS(linear)+MMSE(diag)", "pattern_group": group, "patterns": npat,
                        "host_plan_build_s": round(t_plan, 2), "host_plan_workers": workers,
+                       "output_placement": placement,
                        "rng": "Philox4x32-10 on device", "outputs": names, "parallelism": f"frames sharded x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "frame_kernel",

@@ -288,6 +288,49 @@ class Engine:
             self.check_status()       # synchronises; pass check=False inside timed loops
         return res
 
+    # ---- output placement ---------------------------------------------------------------------------------
+    PLACEMENT_GROUPS = (("tx", "rx", "H", "pilot_symbols", "pilot_mask"), ("H_ls", "H_mmse"))
+
+    def place_outputs(self, descs, outputs=ALL_OUTPUTS, seed=0, tries=4):
+        """Allocate the output tensors for repeated ``run_frames(..., out=...)`` calls, choosing WHERE they live.
+
+        On MI355X the rate at which the frame kernel's concurrent write streams drain depends on the physical placement
+        of the buffers it writes: the same kernel, process and clock measures 2.35 to 3.3 ms per 10 000 frames depending
+        only on which allocations it was handed (tools/placement_test.py; a pure-store model shows the same two levels,
+        about 5.2 and 6.7 TB/s, per tensor group: tools/micro/store_placement.hip).  A long-running job writes into the
+        same buffers for every batch, so it pays to pick them once: this allocates ``tries`` candidate sets per group
+        (synthesis tensors tx/rx/H/..., estimate tensors H_ls/H_mmse; all kept alive meanwhile, so each gets different
+        memory), times the complete kernel on every combination with the library's HIP events, keeps the fastest
+        combination and frees the rest.  Returns (tensors, report)."""
+        outputs = list(outputs)
+        tries = max(1, int(tries))
+        groups = [[n for n in g if n in outputs] for g in self.PLACEMENT_GROUPS]
+        rest = [n for n in outputs if not any(n in g for g in self.PLACEMENT_GROUPS)]
+        cands = [[self.run_frames(descs, seed=seed, outputs=names + (rest if gi == 0 else []), check=False) if names or (gi == 0 and rest)
+                  else {} for _ in range(tries)] for gi, names in enumerate(groups)]
+        self.check_status()
+        timing = {}
+        for i, a in enumerate(cands[0]):
+            for j, b in enumerate(cands[1]):
+                if not b and j > 0:
+                    continue
+                out = {**a, **b}
+                ts = []
+                for _ in range(3):
+                    self.profile_begin(1)
+                    self.run_frames(descs, seed=seed, outputs=outputs, out=out, check=False)
+                    ts.append(self.profile_read()[1])
+                timing[(i, j)] = float(np.median(ts[1:]))
+        self.profile_begin(0)
+        (bi, bj), best = min(timing.items(), key=lambda kv: kv[1])
+        chosen = {**cands[0][bi], **cands[1][bj]}
+        vals = sorted(timing.values())
+        report = {"combinations": len(vals), "kernel_ms_best": round(vals[0], 4), "kernel_ms_median": round(vals[len(vals) // 2], 4),
+                  "kernel_ms_worst": round(vals[-1], 4), "first_allocation_ms": round(timing[(0, 0)], 4)}
+        del cands, out
+        torch.cuda.empty_cache()                                                      # hand the losers back to the driver
+        return chosen, report
+
     # ---- stand-alone estimator surface ---------------------------------------------------------------
     def estimate(self, rx4d, tx_pilots, slot, mmse=False, snr_db=10.0):
         g = self.geom

@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""In-process A/B of library switches that are read from the environment at every launch (CHEST_NO_FAST_PATH,
+CHEST_NO_XCD_REMAP, ...): alternates the two settings step by step inside ONE process on ONE GPU, so clock / box
+differences cancel.  Reports the frame kernel's own duration (library HIP events) per setting.
+
+    python tools/ab_inprocess.py CHEST_NO_FAST_PATH [--rounds 30] [--frames 10000]
+"""
+import argparse
+import importlib
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+PKG = "channel-estimation-in-5g-network_amd"
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("var")
+    ap.add_argument("--rounds", type=int, default=30)
+    ap.add_argument("--frames", type=int, default=10000)
+    args = ap.parse_args()
+    import torch
+    E = importlib.import_module(PKG + ".engine")
+    geom = E.Geometry()
+    eng = E.Engine(geom, 0)
+    G = geom.grid
+    P = int(G * 0.1)
+    F = args.frames
+    slots = []
+    for gidx in range((F + 1023) // 1024):
+        perm = np.arange(G)
+        np.random.RandomState(2024 + gidx).shuffle(perm)
+        slots.append(eng.pattern_slot(np.sort(perm[:P]), "linear"))
+    descs = E.make_descs("EVA", 111.1, 10.0, np.asarray(slots, dtype=np.int32)[np.arange(F) // 1024], n=F)
+    d_dev = torch.from_numpy(descs.view(np.uint8).copy()).to(eng.device)
+    names = ["tx", "rx", "H", "H_ls", "H_mmse", "pilot_symbols", "pilot_mask"]
+    out = eng.run_frames(d_dev, seed=1, outputs=names)
+    res = {0: [], 1: []}
+    for i in range(args.rounds * 2 + 4):
+        setting = i & 1
+        if setting:
+            os.environ[args.var] = "1"
+        else:
+            os.environ.pop(args.var, None)
+        eng.profile_begin(1)
+        eng.run_frames(d_dev, seed=1, frame_offset=i * F, outputs=names, out=out, check=False)
+        _, k_ms, _ = eng.profile_read()
+        if i >= 4:
+            res[setting].append(k_ms)
+    os.environ.pop(args.var, None)
+    a, b = np.array(res[0]), np.array(res[1])
+    print(f"{args.var} unset: frame_kernel {a.mean():.4f} ms (min {a.min():.4f}, sd {a.std():.4f});  "
+          f"set: {b.mean():.4f} ms (min {b.min():.4f}, sd {b.std():.4f});  unset/set = {a.mean() / b.mean():.4f}")
+
+
+if __name__ == "__main__":
+    main()
