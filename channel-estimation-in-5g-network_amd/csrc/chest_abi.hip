@@ -262,14 +262,15 @@ static int pattern_set_impl(chest_ctx* ctx, int32_t slot, const int32_t* pilot_i
             recs[g] = Rec{w0, w1, i0 | (i1 << 16), i2 | (valid << 16)};
         }
     }
-    // block layout: slot[G] u16 | pilot_idx[P] | simplices[ns][3] (triangulation path) | plan[G] records (last, so the
+    // block layout: slot[G] u16 | pilot_idx[P] | simplices[ns][3] + their packed form (triangulation path) | plan[G] records (last, so the
     // triangulation path uploads everything before it in one copy and the device fills the plan)
     const size_t o_slot = 0;
     const size_t o_pil = up16(o_slot + (size_t)G * 2);
     const size_t o_simp = up16(o_pil + (size_t)P * 4);
-    const size_t o_plan = (o_simp + (simplices ? (size_t)ns * 12 : 0) + 255) & ~(size_t)255;
+    const size_t o_pack = up16(o_simp + (simplices ? (size_t)ns * 12 : 0));            // packed simplices, written by the device
+    const size_t o_plan = (o_pack + (simplices ? (size_t)ns * 16 : 0) + 255) & ~(size_t)255;
     const size_t total = up16(o_plan + (with_plan ? (size_t)G * sizeof(Rec) : 0));
-    const size_t upload = plan_idx ? total : o_plan;
+    const size_t upload = plan_idx ? total : o_pack;
     unsigned char* blk = nullptr;
     CHEST_HIP(hipMalloc((void**)&blk, total));
     std::vector<unsigned char> host(upload, 0);
@@ -284,7 +285,8 @@ static int pattern_set_impl(chest_ctx* ctx, int32_t slot, const int32_t* pilot_i
     }
     if (simplices) {
         // point location + barycentric weights on the device (plan_kernels.hip); synchronous like the uploads around it
-        int rc = launch_plan_locate(ctx, nullptr, (const int32_t*)(blk + o_pil), (const int32_t*)(blk + o_simp), ns, blk + o_plan);
+        int rc = launch_plan_locate(ctx, nullptr, (const int32_t*)(blk + o_pil), (const int32_t*)(blk + o_simp), ns, blk + o_pack,
+                                    blk + o_plan);
         if (rc == CHEST_OK && hipStreamSynchronize(nullptr) != hipSuccess) { set_error("plan construction failed"); rc = CHEST_EHIP; }
         if (rc != CHEST_OK) { (void)hipFree(blk); return rc; }
     }

@@ -116,7 +116,8 @@ int launch_tdl(chest_ctx* ctx, hipStream_t st, int32_t type, int64_t ns, int32_t
                float* y);
 int launch_pack_ml(chest_ctx* ctx, hipStream_t st, int32_t B, const float* rx, const float* Hls, const float* Htrue,
                    const uint8_t* mask, int32_t normalize, float* inputs, float* targets);
-int launch_plan_locate(chest_ctx* ctx, hipStream_t st, const int32_t* d_pilot_idx, const int32_t* d_simp, int32_t ns, void* d_plan);
+int launch_plan_locate(chest_ctx* ctx, hipStream_t st, const int32_t* d_pilot_idx, const int32_t* d_simp, int32_t ns, void* d_packed,
+                       void* d_plan);
 struct QamTable;
 int qam_table(int32_t M, QamTable* t);
 int launch_qam_mod(chest_ctx* ctx, hipStream_t st, int32_t M, int64_t n, const uint8_t* bits, int32_t wide, void* out);

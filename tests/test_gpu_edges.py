@@ -208,3 +208,23 @@ def test_full_covariance_mmse_at_baseline_sizes(N, cp, U, T, R, B):
             want = O._griddata_complex(Wref @ h_ls, pos, (S, nsc), "linear")
             for t in (0, T - 1):
                 assert relerr(got[b, :, r, t, :], want) < TOL
+
+
+def test_place_outputs_returns_usable_buffers():
+    """Engine.place_outputs only chooses WHERE the output tensors live: the buffers it returns have the documented shapes
+    and a run into them equals a run into fresh allocations bit for bit."""
+    geom = E.Geometry()
+    eng = E.get_engine(geom, 0)
+    pil = np.sort(np.random.RandomState(3).permutation(geom.grid)[:838])
+    slot = eng.pattern_slot(pil, "linear")
+    descs = E.make_descs("EVA", 111.1, 10.0, slot, n=48)
+    names = ["tx", "rx", "H", "H_ls", "H_mmse", "pilot_symbols", "pilot_mask", "metrics"]
+    out, rep = eng.place_outputs(descs, names, seed=5, tries=2)
+    assert set(out) == set(names) and rep["combinations"] == 4
+    assert rep["kernel_ms_best"] <= rep["kernel_ms_median"] <= rep["kernel_ms_worst"]
+    eng.run_frames(descs, seed=5, frame_offset=7, outputs=names, out=out)
+    ref = eng.run_frames(descs, seed=5, frame_offset=7, outputs=names)
+    for n in names:
+        assert out[n].shape == ref[n].shape and torch.equal(out[n], ref[n]), n
+    only, rep1 = eng.place_outputs(descs, ["H_ls"], seed=5, tries=1)
+    assert list(only) == ["H_ls"] and rep1["combinations"] == 1
