@@ -51,7 +51,11 @@ def main():
         "rx + estimates": ["rx", "H_ls", "H_mmse"],
         "metrics only (no tensor stores)": ["metrics"],
     }
-    outs = {k: eng.run_frames(d_dev, seed=1, outputs=v) for k, v in variants.items()}
+    # ONE set of output tensors, placed once (Engine.place_outputs) and shared by every variant: the time of this kernel
+    # depends on where its outputs live, so separate allocations per variant would confound the comparison.
+    placed, rep = eng.place_outputs(d_dev, full + ["metrics"], seed=1, tries=4)
+    print("placement:", rep)
+    outs = {k: {n: placed[n] for n in v} for k, v in variants.items()}
     t = {k: [] for k in variants}
     for i in range(args.rounds + 2):
         for k, v in variants.items():
