@@ -516,7 +516,8 @@ static size_t k2_lds_bytes(int nch, int Pmax, int R) {
 static int launch_k2(chest_ctx* ctx, hipStream_t st, int32_t B, int nch, const chest_frame_desc* descs, int Pmax,
                      uint64_t seed, uint64_t frame_offset, const chest_injected& inj, const chest_frame_outputs& out,
                      const float* workspace) {
-    const size_t lds2 = k2_lds_bytes(nch, Pmax, ctx->fp.R);
+    size_t lds2 = k2_lds_bytes(nch, Pmax, ctx->fp.R);
+    if (const char* pad = getenv("CHEST_K2_LDS_PAD")) lds2 += (size_t)atol(pad);      // experiment: lower the occupancy
     if (lds2 > 160 * 1024) { set_error("frame kernel needs %zu B of LDS (> 160 KiB): too many antennas or pilots", lds2); return CHEST_EINVAL; }
     CHEST_LDS_OPT_IN(ctx, LDS_FRAME, frame_kernel, lds2);
     hipLaunchKernelGGL(frame_kernel, dim3(B), dim3(ctx->block_threads), lds2, st, ctx->d_fp, descs, ctx->d_patterns,
