@@ -451,7 +451,14 @@ frame_kernel(const FrameParams* __restrict__ fpp, const chest_frame_desc* __rest
         // Workgroups are dealt round-robin over the 8 XCDs (b % 8 labels the blocks that share one).  Give each XCD a
         // contiguous frame range: its L2 then holds one pattern group's tables and its writes are one sequential region.
         const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, x = b & 7;
-        b = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);      // bijective for any grid size
+        if (xcd_remap == 1) {
+            b = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);  // bijective for any grid size
+        } else {
+            // experiment (CHEST_XCD_BLOCK=n): XCD x takes blocks of n consecutive frames round-robin; frames past the last
+            // full group of 8 blocks keep their identity mapping
+            const int n = xcd_remap, full = (nwg / (8 * n)) * (8 * n), i = b >> 3;
+            if (b < full) b = (i / n) * (8 * n) + x * n + (i % n);
+        }
     }
     const int S = fp.S, T = fp.T, R = fp.R, nsc = fp.nsc, G = fp.G;
     const float* rec = state + (size_t)b * frame_state_floats(S, R, T);
@@ -521,7 +528,8 @@ static int launch_k2(chest_ctx* ctx, hipStream_t st, int32_t B, int nch, const c
     if (lds2 > 160 * 1024) { set_error("frame kernel needs %zu B of LDS (> 160 KiB): too many antennas or pilots", lds2); return CHEST_EINVAL; }
     CHEST_LDS_OPT_IN(ctx, LDS_FRAME, frame_kernel, lds2);
     hipLaunchKernelGGL(frame_kernel, dim3(B), dim3(ctx->block_threads), lds2, st, ctx->d_fp, descs, ctx->d_patterns,
-                       Pmax, seed, frame_offset, inj, out, workspace, nch, getenv("CHEST_NO_XCD_REMAP") ? 0 : 1, ctx->d_status);
+                       Pmax, seed, frame_offset, inj, out, workspace, nch, getenv("CHEST_NO_XCD_REMAP") ? 0 : (getenv("CHEST_XCD_BLOCK") ? atoi(getenv("CHEST_XCD_BLOCK")) : 1),
+                       ctx->d_status);
     return CHEST_OK;
 }
 
