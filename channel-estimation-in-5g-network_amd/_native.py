@@ -94,6 +94,10 @@ def lib():
             raise ChestError(
                 f"{LIB_PATH} is missing: build the HIP extension first "
                 "(python -c 'import __graft_entry__ as g; g.build()' or make -C <package>/csrc)")
+        # Load torch's HIP runtime BEFORE libchest.so: the PyTorch wheel ships its own libamdhip64, and whichever copy is
+        # mapped first serves the whole process.  If libchest.so pulled in /opt/rocm's copy first, a later `import torch`
+        # would leave two runtimes behind and chest_create would fail with "no ROCm-capable device is detected".
+        import torch  # noqa: F401
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)
