@@ -40,7 +40,8 @@ class Injected(C.Structure):
 class FrameOutputs(C.Structure):
     _fields_ = [("tx", C.c_void_p), ("rx", C.c_void_p), ("H", C.c_void_p), ("H_ls", C.c_void_p),
                 ("H_mmse", C.c_void_p), ("pilot_symbols", C.c_void_p), ("pilot_mask", C.c_void_p),
-                ("metrics", C.c_void_p), ("pilot_stride", C.c_int32)]
+                ("metrics", C.c_void_p), ("pilot_stride", C.c_int32), ("h_ls_stride", C.c_int32),
+                ("h_ls_pilots", C.c_void_p)]
 
 
 # name -> (restype, argtypes); this table is also what tests/test_abi_symbols.py checks against chest.h
@@ -78,6 +79,7 @@ SIGNATURES = {
     "chest_mmse_full_prepare": (_i32, [_vp, _vp, _i32, _vp, _f, _vp, _vp, _i64]),
     "chest_mmse_full_workspace_bytes": (_i64, [_i32]),
     "chest_mmse_full_apply_scratch_bytes": (_i64, [_i32, _i32]),
+    "chest_mmse_full_apply_pilots": (_i32, [_vp, _vp, _i32, _vp, _i32, _i32, _vp, _vp, _vp]),
     "chest_estimate_dense_scratch_bytes": (_i64, [_vp, _i32, _i32]),
     "chest_estimate_dense": (_i32, [_vp, _vp, _i32, _vp, _vp, _i32, _i32, _vp, _vp, _vp]),
     "chest_mmse_full_apply": (_i32, [_vp, _vp, _i32, _vp, _vp, _i32, _i32, _vp, _vp, _vp]),

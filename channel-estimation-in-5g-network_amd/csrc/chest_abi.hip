@@ -406,6 +406,11 @@ int chest_frames_run(chest_ctx* ctx, void* stream, int32_t B, const chest_frame_
         for (const auto& p : ctx->patterns) Pmax = p.dev.P > Pmax ? p.dev.P : Pmax;
         if (out->pilot_stride < Pmax) { set_error("pilot_stride %d < largest pattern %d", out->pilot_stride, Pmax); return CHEST_EINVAL; }
     }
+    if (out->h_ls_pilots != nullptr) {
+        int Pmax = 0;
+        for (const auto& p : ctx->patterns) Pmax = p.dev.P > Pmax ? p.dev.P : Pmax;
+        if (out->h_ls_stride < Pmax) { set_error("h_ls_stride %d < largest pattern %d", out->h_ls_stride, Pmax); return CHEST_EINVAL; }
+    }
     return launch_frames(ctx, (hipStream_t)stream, B, descs, seed, frame_offset, inj, out, workspace, workspace_bytes);
 }
 

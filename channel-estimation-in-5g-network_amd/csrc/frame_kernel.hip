@@ -345,8 +345,16 @@ __device__ __forceinline__ void frame_body(const FrameArgs& A, int nch) {
     }
     const bool want_metrics = out.metrics != nullptr;
     const bool want_est = (Lb != nullptr) || (Mb != nullptr) || want_metrics;
-    if (!want_est) return;
+    if (!want_est && out.h_ls_pilots == nullptr) return;
     __syncthreads();
+    if (out.h_ls_pilots != nullptr) {                // LS estimates at the pilots, [R][stride] per frame, zero padded
+        float2* __restrict__ hl = (float2*)out.h_ls_pilots + (size_t)b * R * out.h_ls_stride;
+        for (int i = tid; i < R * out.h_ls_stride; i += blockDim.x) {
+            const int r = i / out.h_ls_stride, p = i - r * out.h_ls_stride;
+            hl[i] = p < P ? hp[p * R + r] : make_float2(0.f, 0.f);
+        }
+    }
+    if (!want_est) return;
 
     // ---- MMSE shrinkage per rx: p = mean|h_ls|^2, alpha = p/(p+sigma^2) (:177-190, scalar form) ---
     for (int r = 0; r < R; ++r) {

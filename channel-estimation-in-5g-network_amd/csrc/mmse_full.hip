@@ -390,14 +390,17 @@ pack_w_kernel(int P, int Kpad, const float2* __restrict__ W, float2* __restrict_
 }
 
 // plan-driven interpolation of precomputed pilot values h[m][Ppad] (same arithmetic as estimate_kernel)
+// tfold == 0: one block per grid m = (b*R + r)*T + t.  tfold != 0: one block per (b, r); its result is written to all T
+// grids of that rx (the reference's callers repeat rx over tx, quirk Q9, so those grids are identical).
 __global__ void __launch_bounds__(256)
 interp_from_pilots_kernel(int S, int R, int T, int nsc, int Ppad, const PatternDev* __restrict__ patterns, int slot,
-                          const float2* __restrict__ h, float2* __restrict__ H_est) {
+                          const float2* __restrict__ h, float2* __restrict__ H_est, int tfold) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     float2* hp = (float2*)lds_raw;
     const PatternDev pat = patterns[slot];
     const int P = pat.P, G = S * nsc, m = blockIdx.x;
-    const int t = m % T, r = (m / T) % R, b = m / (T * R);
+    const int t0 = tfold ? 0 : m % T, nt = tfold ? T : 1;
+    const int r = tfold ? m % R : (m / T) % R, b = tfold ? m / R : m / (T * R);
     for (int i = threadIdx.x; i < P; i += blockDim.x) hp[i] = h[(size_t)m * Ppad + i];
     __syncthreads();
     const PlanRec* __restrict__ plan = (const PlanRec*)pat.plan;
@@ -405,8 +408,15 @@ interp_from_pilots_kernel(int S, int R, int T, int nsc, int Ppad, const PatternD
     for (int g = threadIdx.x; g < G; g += blockDim.x) {
         const float2 v = interp(plan[g], hp, 1, 0);
         const int s = g / nsc, k = g - s * nsc;
-        H_est[frame_base + ((size_t)(s * R + r) * T + t) * nsc + k] = v;
+        for (int t = t0; t < t0 + nt; ++t) H_est[frame_base + ((size_t)(s * R + r) * T + t) * nsc + k] = v;
     }
+}
+
+// h_ls_pilots [M][stride] (as chest_frames_run writes it) -> GEMM A operand [Mpad][Ppad], zero padded
+__global__ void __launch_bounds__(256)
+pack_h_kernel(int M, int P, int stride, int Ppad, const float2* __restrict__ h, float2* __restrict__ hp) {
+    const int m = blockIdx.x;
+    for (int i = threadIdx.x; i < Ppad; i += blockDim.x) hp[(size_t)m * Ppad + i] = (m < M && i < P) ? h[(size_t)m * stride + i] : make_float2(0.f, 0.f);
 }
 
 // Dense interpolation operator (Clough-Tocher 'cubic', interp_plan.cubic_operator): H[m][g] = sum_p A[g][p] h[m][p],
@@ -642,7 +652,41 @@ int chest_mmse_full_apply(chest_ctx* ctx, void* stream, int32_t B, const float* 
     const size_t lds = (size_t)P * sizeof(float2);
     CHEST_LDS_OPT_IN(ctx, LDS_INTERP, interp_from_pilots_kernel, lds);
     hipLaunchKernelGGL(interp_from_pilots_kernel, dim3(M), dim3(256), lds, st, f.S, f.R, f.T, f.nsc, Ppad, ctx->d_patterns,
-                       slot, h_out, (float2*)H_est);
+                       slot, h_out, (float2*)H_est, 0);
+    CHEST_HIP(hipGetLastError());
+    return CHEST_OK;
+}
+
+int chest_mmse_full_apply_pilots(chest_ctx* ctx, void* stream, int32_t B, const float* h_ls_pilots, int32_t h_ls_stride,
+                                 int32_t slot, const float* W, float* h_scratch, float* H_est) {
+    if (!ctx || B < 0 || (B > 0 && (!h_ls_pilots || !W || !h_scratch || !H_est))) {
+        set_error("chest_mmse_full_apply_pilots: bad argument");
+        return CHEST_EINVAL;
+    }
+    if (B == 0) return CHEST_OK;
+    if (slot < 0 || slot >= (int)ctx->patterns.size() || ctx->patterns[slot].dev.slot == nullptr ||
+        ctx->patterns[slot].dev.plan == nullptr) {
+        set_error("pattern slot %d is not set or has no plan", slot);
+        return CHEST_ESTATE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const auto& f = ctx->fp;
+    const PatternDev& pd = ctx->patterns[slot].dev;
+    const int P = pd.P, Ppad = pad16(P), M = B * f.R;                     // one right-hand side per (frame, rx)
+    if (h_ls_stride < P) { set_error("h_ls_stride %d < %d pilots", h_ls_stride, P); return CHEST_EINVAL; }
+    const int Mpad = pad128(M), Npad = pad128(P);
+    float2* h_in = (float2*)h_scratch;
+    float2* h_out = h_in + (size_t)Mpad * Ppad;
+    float2* w_packed = h_out + (size_t)M * Ppad;
+    hipLaunchKernelGGL(pack_h_kernel, dim3(Mpad), dim3(256), 0, st, M, P, h_ls_stride, Ppad, (const float2*)h_ls_pilots, h_in);
+    hipLaunchKernelGGL(pack_w_kernel, dim3(Npad), dim3(256), 0, st, P, Ppad, (const float2*)W, w_packed);
+    CHEST_LDS_OPT_IN(ctx, LDS_GEMM3M, cgemm_w_kernel_3m, T3_LDS_BYTES);
+    hipLaunchKernelGGL(cgemm_w_kernel_3m, dim3(Npad / T2_N, Mpad / T2_M), dim3(256), T3_LDS_BYTES, st, P, Ppad, M, Ppad,
+                       (const float2*)w_packed, h_in, h_out);
+    const size_t lds = (size_t)P * sizeof(float2);
+    CHEST_LDS_OPT_IN(ctx, LDS_INTERP, interp_from_pilots_kernel, lds);
+    hipLaunchKernelGGL(interp_from_pilots_kernel, dim3(M), dim3(256), lds, st, f.S, f.R, f.T, f.nsc, Ppad, ctx->d_patterns,
+                       slot, h_out, (float2*)H_est, 1);
     CHEST_HIP(hipGetLastError());
     return CHEST_OK;
 }

@@ -243,10 +243,12 @@ class Engine:
         shapes = {"tx": ((B, S, T, nsc), torch.complex64), "rx": ((B, S, R, nsc), torch.complex64),
                   "H": ((B, S, R, T, nsc), torch.complex64), "H_ls": ((B, S, R, T, nsc), torch.complex64),
                   "H_mmse": ((B, S, R, T, nsc), torch.complex64), "pilot_symbols": ((B, pmax), torch.complex64),
-                  "pilot_mask": ((B, S, nsc), torch.uint8), "metrics": ((B, N.NUM_METRICS), torch.float32)}
+                  "pilot_mask": ((B, S, nsc), torch.uint8), "metrics": ((B, N.NUM_METRICS), torch.float32),
+                  "h_ls_pilots": ((B, R, (pmax + 15) // 16 * 16), torch.complex64)}
         res = {} if out is None else dict(out)
         fo = N.FrameOutputs()
         fo.pilot_stride = pmax
+        fo.h_ls_stride = (pmax + 15) // 16 * 16
         for name in outputs:
             if name not in shapes:
                 raise ValueError(f"unknown output {name!r}")
@@ -392,6 +394,26 @@ class Engine:
         N.check(N.lib().chest_mmse_full_apply(self._h, self._stream(), B, rx.data_ptr(), tp.data_ptr(), stride, int(slot),
                                               W.contiguous().data_ptr(), scratch.data_ptr(), out.data_ptr()),
                 "chest_mmse_full_apply")
+        torch.cuda.current_stream(self.device).synchronize()       # scratch is freed on return
+        return out
+
+    def mmse_full_apply_pilots(self, h_ls_pilots, slot, W):
+        """Full-covariance MMSE for frames produced by ``run_frames(..., outputs=[..., "h_ls_pilots"])``: one right-hand
+        side per (frame, rx) instead of per (frame, rx, tx) -- the reference's callers repeat rx over tx, so the T grids of
+        an rx antenna are identical -- and every result written T times.  Returns H_mmse [B,S,R,T,nsc]."""
+        g = self.geom
+        h = self._c64(h_ls_pilots)
+        P = self.num_pilots(slot)
+        if h.dim() != 3 or h.shape[1] != g.num_rx or h.shape[2] < P:
+            raise ValueError(f"h_ls_pilots must be [B, {g.num_rx}, >= {P}]")
+        if tuple(W.shape) != (P, P):
+            raise ValueError(f"W must be [{P}, {P}] for this pattern")
+        B = h.shape[0]
+        scratch = torch.empty(N.lib().chest_mmse_full_apply_scratch_bytes(P, B * g.num_rx), dtype=torch.uint8, device=self.device)
+        out = self.empty_c64(B, g.num_symbols, g.num_rx, g.num_tx, g.num_sc)
+        N.check(N.lib().chest_mmse_full_apply_pilots(self._h, self._stream(), B, h.data_ptr(), h.shape[2], int(slot),
+                                                     W.contiguous().data_ptr(), scratch.data_ptr(), out.data_ptr()),
+                "chest_mmse_full_apply_pilots")
         torch.cuda.current_stream(self.device).synchronize()       # scratch is freed on return
         return out
 

@@ -93,6 +93,10 @@ typedef struct chest_frame_outputs {
     uint8_t* pilot_mask;         /* [B][G] 0/1 */
     float* metrics;              /* [B][CHEST_NUM_METRICS] see below */
     int32_t pilot_stride;
+    int32_t h_ls_stride;         /* elements per (frame, rx) row of h_ls_pilots, >= P */
+    float* h_ls_pilots;          /* [B][R][h_ls_stride] c64: LS estimates at the pilots, y_p / (x_p + 1e-12), in pilot order
+                                  * (what LSEstimator.estimate_at_pilots yields for every tx of that rx, quirk Q9); entries
+                                  * P..h_ls_stride-1 are written as 0.  Input of chest_mmse_full_apply_pilots. */
 } chest_frame_outputs;
 
 /* metrics[b][*] (float32) */
@@ -249,6 +253,14 @@ int64_t chest_mmse_full_apply_scratch_bytes(int32_t num_pilots, int32_t num_grid
 int chest_mmse_full_apply(chest_ctx* ctx, void* stream, int32_t num_frames, const float* rx4d,
                           const float* tx_pilots, int32_t pilot_stride, int32_t pattern_slot,
                           const float* W, float* h_scratch /* chest_mmse_full_apply_scratch_bytes(P, B*R*T) */, float* H_est);
+
+/* The same for frames that come out of chest_frames_run: h_ls_pilots [B][R][h_ls_stride] as that call writes it.  Every
+ * caller of the reference repeats rx over tx (src/dataset_generator.py:63-64), so the R*T grids of a frame hold only R
+ * different right-hand sides; this entry point multiplies B*R rows instead of B*R*T and writes each result T times
+ * (H_est [B][S][R][T][nsc]) -- identical values, 1/T of the matrix work and no gather from a [B][S][R][T][nsc] input.
+ * scratch: chest_mmse_full_apply_scratch_bytes(P, B*R) bytes. */
+int chest_mmse_full_apply_pilots(chest_ctx* ctx, void* stream, int32_t num_frames, const float* h_ls_pilots,
+                                 int32_t h_ls_stride, int32_t pattern_slot, const float* W, float* h_scratch, float* H_est);
 
 /* LSEstimator('cubic').estimate (src/baseline_estimators.py:65-79 with method='cubic' = scipy Clough-Tocher): the
  * interpolation is a dense linear operator A [G][P] float32 (DEVICE; built on the host once per pattern from scipy's own

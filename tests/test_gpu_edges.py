@@ -195,10 +195,18 @@ def test_full_covariance_mmse_at_baseline_sizes(N, cp, U, T, R, B):
     W = eng.mmse_full_prepare(cov, snr)
     Wref = cov @ np.linalg.inv(cov + 10 ** (-snr / 10) * np.eye(P))
     assert relerr(W.cpu().numpy(), Wref) < 1e-6
-    sim = eng.run_frames(E.make_descs("ETU", 555.6, snr, slot, n=B), seed=9, outputs=("rx", "pilot_symbols"))
+    sim = eng.run_frames(E.make_descs("ETU", 555.6, snr, slot, n=B), seed=9, outputs=("rx", "pilot_symbols", "h_ls_pilots"))
     rx4 = sim["rx"][:, :, :, None, :].expand(B, S, R, T, nsc).contiguous()
     xp = sim["pilot_symbols"][:, :P].contiguous()
-    got = eng.mmse_full_apply(rx4, xp, slot, W).cpu().numpy()
+    got_t = eng.mmse_full_apply(rx4, xp, slot, W)
+    got = got_t.cpu().numpy()
+    # the pipeline's own route: LS pilot estimates straight from the frame kernel, one right-hand side per (frame, rx),
+    # results written T times -- must give the same tensor as the generic per-(rx, tx) route
+    hls = sim["h_ls_pilots"]
+    assert hls.shape[:2] == (B, R) and hls.shape[2] >= P and float(hls[:, :, P:].abs().max() if hls.shape[2] > P else 0.0) == 0.0
+    via_pilots = eng.mmse_full_apply_pilots(hls, slot, W)
+    assert via_pilots.shape == got_t.shape
+    assert float((via_pilots - got_t).abs().max() / got_t.abs().max()) < 2e-6
     rx_h, xp_h = sim["rx"].cpu().numpy().astype(np.complex128), xp.cpu().numpy().astype(np.complex128)
     ps, pk = np.unravel_index(pil, (S, nsc))
     mask, pos = O.pattern_from_indices(pil, S, nsc)[1], O.pattern_from_indices(pil, S, nsc)[0]

@@ -55,6 +55,20 @@ for (N, cp, U, T, R, B) in (_cases[1:] if _args.only_big else _cases):
           f"{B / ms * 1e3:9.0f} frames/s, {flops / ms * 1e-9:6.1f} TFLOP/s of 157.3 (whole apply: gather + GEMM + interpolation)", flush=True)
     # comparator (not the product): rocBLAS through torch on the same shapes -- complex64 cgemm W @ X and a float32
     # sgemm with the same real flop count -- to see what the library sustains on this box
+    # the pipeline's own route: h_ls at the pilots straight from the frame kernel, B*R right-hand sides, T-fold stores
+    sim2 = eng.run_frames(d, seed=3, outputs=("h_ls_pilots",))
+    hls = sim2["h_ls_pilots"]
+    out2 = eng.mmse_full_apply_pilots(hls, slot, W)
+    torch.cuda.synchronize()
+    a.record()
+    for _ in range(3):
+        out2 = eng.mmse_full_apply_pilots(hls, slot, W)
+    b.record(); torch.cuda.synchronize()
+    ms2 = a.elapsed_time(b) / 3
+    same = float((out2 - out).abs().max() / out.abs().max())
+    print(f"      from the frame kernel's pilot estimates (B*R right-hand sides, T-fold stores): apply {B} frames {ms2:8.2f} ms = "
+          f"{B / ms2 * 1e3:9.0f} frames/s  (max difference to the per-(rx,tx) route {same:.1e})", flush=True)
+    del sim2, hls, out2
     if _args.no_rocblas:
         del eng
         continue
