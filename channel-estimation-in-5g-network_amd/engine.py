@@ -92,6 +92,7 @@ class Engine:
         self._slot_P = {}
         self._next_slot = 0
         self.max_cached_patterns = 4096
+        self._stage, self._stage_i, self._stage_pending = [None, None], 0, None     # pinned descriptor staging (run_frames)
         self._workspace = None
         self._dense = {}          # pattern key -> dense interpolation operator on the device
         nsc = C.c_int32()
@@ -237,7 +238,7 @@ class Engine:
         else:
             descs = np.ascontiguousarray(descs, dtype=DESC_DTYPE)
             B = len(descs)
-            d_dev = torch.from_numpy(descs.view(np.uint8).copy()).to(self.device)
+            d_dev = self._stage_descs(descs)
         S, T, R, nsc, G = g.num_symbols, g.num_tx, g.num_rx, g.num_sc, g.grid
         pmax = max(self._slot_P.values()) if self._slot_P else 0
         shapes = {"tx": ((B, S, T, nsc), torch.complex64), "rx": ((B, S, R, nsc), torch.complex64),
@@ -286,9 +287,32 @@ class Engine:
         N.check(N.lib().chest_frames_run(self._h, self._stream(), B, d_dev.data_ptr(), int(seed) & (2**64 - 1),
                                          int(frame_offset), inj_p, C.byref(fo), self._workspace.data_ptr(),
                                          self._workspace.numel()), "chest_frames_run")
+        if self._stage_pending is not None:
+            self._stage_pending.record()          # this launch has consumed the staged descriptors
+            self._stage_pending = None
         if check:
             self.check_status()       # synchronises; pass check=False inside timed loops
         return res
+
+    def _stage_descs(self, descs):
+        """Host descriptors -> device through one of two pinned staging buffers, asynchronously on the launch stream.
+        (A pageable ``.to(device)`` copy is stream-ordered AND blocks the host, i.e. every call would first wait for the
+        previous launch to finish.)"""
+        nbytes = descs.nbytes
+        self._stage_i ^= 1
+        st = self._stage[self._stage_i]
+        if st is None or st[0].numel() < nbytes:
+            cap = max(nbytes, 1 << 16)
+            st = [torch.empty(cap, dtype=torch.uint8).pin_memory(), torch.empty(cap, dtype=torch.uint8, device=self.device),
+                  torch.cuda.Event()]
+            st[2].record()
+            self._stage[self._stage_i] = st
+        pin, dev, ev = st
+        ev.synchronize()                          # the launch that last read this pair has finished
+        pin.numpy()[:nbytes] = descs.view(np.uint8).reshape(-1)
+        dev[:nbytes].copy_(pin[:nbytes], non_blocking=True)
+        self._stage_pending = ev
+        return dev[:nbytes]
 
     # ---- output placement ---------------------------------------------------------------------------------
     PLACEMENT_GROUPS = (("tx", "rx", "H", "pilot_symbols", "pilot_mask"), ("H_ls", "H_mmse"))
