@@ -332,8 +332,17 @@ class Engine:
         tries = max(1, int(tries))
         groups = [[n for n in g if n in outputs] for g in self.PLACEMENT_GROUPS]
         rest = [n for n in outputs if not any(n in g for g in self.PLACEMENT_GROUPS)]
-        cands = [[self.run_frames(descs, seed=seed, outputs=names + (rest if gi == 0 else []), check=False) if names or (gi == 0 and rest)
-                  else {} for _ in range(tries)] for gi, names in enumerate(groups)]
+        cands = [[], []]
+        for k in range(tries):                                   # candidate k of both groups, then k + 1: stop early if HBM runs out
+            try:
+                new = [self.run_frames(descs, seed=seed, outputs=names + (rest if gi == 0 else []), check=False)
+                       if names or (gi == 0 and rest) else {} for gi, names in enumerate(groups)]
+            except torch.cuda.OutOfMemoryError:
+                if k == 0:
+                    raise
+                torch.cuda.empty_cache()
+                break
+            cands[0].append(new[0]); cands[1].append(new[1])
         self.check_status()
         timing = {}
         for i, a in enumerate(cands[0]):
