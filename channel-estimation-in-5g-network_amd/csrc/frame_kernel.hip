@@ -461,6 +461,10 @@ frame_kernel(const FrameParams* __restrict__ fpp, const chest_frame_desc* __rest
         const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, x = b & 7;
         if (xcd_remap == 1) {
             b = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);  // bijective for any grid size
+        } else if (xcd_remap < 0) {
+            // experiment (CHEST_FRAME_STRIDE=p, p coprime to the grid size): concurrently running workgroups are spread over the
+            // whole batch instead of forming a moving window
+            b = (int)(((long long)b * (long long)(-xcd_remap)) % nwg);
         } else {
             // experiment (CHEST_XCD_BLOCK=n): XCD x takes blocks of n consecutive frames round-robin; frames past the last
             // full group of 8 blocks keep their identity mapping
@@ -536,7 +540,7 @@ static int launch_k2(chest_ctx* ctx, hipStream_t st, int32_t B, int nch, const c
     if (lds2 > 160 * 1024) { set_error("frame kernel needs %zu B of LDS (> 160 KiB): too many antennas or pilots", lds2); return CHEST_EINVAL; }
     CHEST_LDS_OPT_IN(ctx, LDS_FRAME, frame_kernel, lds2);
     hipLaunchKernelGGL(frame_kernel, dim3(B), dim3(ctx->block_threads), lds2, st, ctx->d_fp, descs, ctx->d_patterns,
-                       Pmax, seed, frame_offset, inj, out, workspace, nch, getenv("CHEST_NO_XCD_REMAP") ? 0 : (getenv("CHEST_XCD_BLOCK") ? atoi(getenv("CHEST_XCD_BLOCK")) : 1),
+                       Pmax, seed, frame_offset, inj, out, workspace, nch, getenv("CHEST_NO_XCD_REMAP") ? 0 : (getenv("CHEST_FRAME_STRIDE") ? -atoi(getenv("CHEST_FRAME_STRIDE")) : (getenv("CHEST_XCD_BLOCK") ? atoi(getenv("CHEST_XCD_BLOCK")) : 1)),
                        ctx->d_status);
     return CHEST_OK;
 }

@@ -24,13 +24,15 @@ sets, pads = [], []
 for i in range(NSETS):
     sets.append(eng.run_frames(d_dev, seed=1, outputs=names))
     pads.append(torch.empty((i + 1) * 123_456_789, dtype=torch.uint8, device=eng.device))
-variants = [None, "2", "8", "32", "128", "512"]            # None = default contiguous eighths; plus identity below
+variants = [None, "32", "512", "s7", "s1249", "s4999"]       # None = default contiguous eighths; "sN" = scatter stride N; plus identity
 res = {}
 for it in range(6):
     for j, o in enumerate(sets):
         for v in variants + ["identity"]:
-            os.environ.pop("CHEST_XCD_BLOCK", None); os.environ.pop("CHEST_NO_XCD_REMAP", None)
-            if v == "identity":
+            os.environ.pop("CHEST_XCD_BLOCK", None); os.environ.pop("CHEST_NO_XCD_REMAP", None); os.environ.pop("CHEST_FRAME_STRIDE", None)
+            if v is not None and v.startswith("s"):
+                os.environ["CHEST_FRAME_STRIDE"] = v[1:]
+            elif v == "identity":
                 os.environ["CHEST_NO_XCD_REMAP"] = "1"
             elif v is not None:
                 os.environ["CHEST_XCD_BLOCK"] = v
@@ -39,8 +41,8 @@ for it in range(6):
             k_ms = eng.profile_read()[1]
             if it >= 1:
                 res.setdefault((j, v), []).append(k_ms)
-os.environ.pop("CHEST_XCD_BLOCK", None); os.environ.pop("CHEST_NO_XCD_REMAP", None)
+os.environ.pop("CHEST_XCD_BLOCK", None); os.environ.pop("CHEST_NO_XCD_REMAP", None); os.environ.pop("CHEST_FRAME_STRIDE", None)
 print("frame_kernel ms; rows = output sets, columns = mapping")
-print("set   " + "".join(f"{('eighths' if v is None else ('block ' + v if v != 'identity' else v)):>11s}" for v in variants + ["identity"]))
+print("set   " + "".join(f"{('eighths' if v is None else (v if v == 'identity' or v.startswith('s') else 'block ' + v)):>11s}" for v in variants + ["identity"]))
 for j in range(NSETS):
     print(f"{j:3d}   " + "".join(f"{np.mean(res[(j, v)]):11.3f}" for v in variants + ["identity"]))
