@@ -155,15 +155,14 @@ def main():
         pils.append(np.sort(perm[:P]))
     t_plan = time.perf_counter()
     workers = args.plan_workers or min(16, os.cpu_count() or 1)
-    if npat >= 4 * workers:                 # Qhull Delaunay on the host (~3 ms per pattern per core); point location on the GPU
-        IP = importlib.import_module(PKG + ".interp_plan")
-        plans = IP.triangulations_parallel(pils, S, nsc, workers)
-    else:
-        workers, plans = 1, [None] * npat
     eng.max_cached_patterns = max(eng.max_cached_patterns, npat + 8)
-    slots = [eng.pattern_slot(pil, "linear", plan=pl) for pil, pl in zip(pils, plans)]
+    if npat >= 4 * workers:                 # Qhull Delaunay on the host (~2 ms per pattern per core); point location on the GPU.
+        IP = importlib.import_module(PKG + ".interp_plan")           # Uploads overlap the pool's remaining triangulations.
+        slots = [eng.pattern_slot(pil, "linear", plan=tri) for pil, tri in zip(pils, IP.triangulations_iter(pils, S, nsc, workers))]
+    else:
+        workers = 1
+        slots = [eng.pattern_slot(pil, "linear") for pil in pils]
     t_plan = time.perf_counter() - t_plan
-    del plans
     slot_of_frame = np.asarray(slots, dtype=np.int32)[np.arange(F) // group]
     descs = E.make_descs(ct, fd, snr, slot_of_frame, n=F)
     d_dev = torch.from_numpy(descs.view(np.uint8).copy()).to(eng.device)

@@ -131,8 +131,9 @@ class ChannelEstimationDataset:
             perm = np.arange(G)
             rs.shuffle(perm)                                                         # PilotPattern's algorithm (:227-229)
             pils.append(np.sort(perm[: int(G * d)]))
-        # Qhull triangulations (~3 ms per pattern per core) optionally in a process pool; the device turns them into plans
-        plans = _interp_plan.triangulations_parallel(pils, S, nsc, plan_workers) if plan_workers > 1 else [None] * len(pils)
+        # Qhull triangulations (~2 ms per pattern per core) optionally in a process pool; the device turns them into plans,
+        # and each upload overlaps the pool's remaining work
+        plans = _interp_plan.triangulations_iter(pils, S, nsc, plan_workers) if plan_workers > 1 else iter([None] * len(pils))
         eng.max_cached_patterns = max(eng.max_cached_patterns, len(keys) + 8)
         for key, pil, plan in zip(keys, pils, plans):
             slots[(pi == key[0]) & (group == key[1])] = eng.pattern_slot(pil, "linear", plan=plan)

@@ -136,6 +136,19 @@ def triangulations_parallel(pilot_idx_list, S, nsc, workers=0):
     return [_tri_job(j) for j in jobs]
 
 
+def triangulations_iter(pilot_idx_list, S, nsc, workers=0):
+    """Like triangulations_parallel, but yields the simplices in input order as they become available, so that the caller
+    can upload pattern i (~0.2 ms of host work) while the pool is still triangulating pattern i + k (~2 ms per core)."""
+    jobs = [(np.asarray(p, dtype=np.int64), S, nsc) for p in pilot_idx_list]
+    if workers and workers > 1 and len(jobs) > 1:
+        import multiprocessing as mp
+        with mp.get_context("spawn").Pool(min(workers, len(jobs))) as pool:
+            yield from pool.imap(_tri_job, jobs, chunksize=max(1, min(64, len(jobs) // (8 * workers))))
+    else:
+        for j in jobs:
+            yield _tri_job(j)
+
+
 def _plan_job(args):
     """Worker entry point of build_plans_parallel (top-level so that it pickles)."""
     pilot_idx, S, nsc, method = args

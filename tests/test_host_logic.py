@@ -205,3 +205,12 @@ def test_exact_integer_point_location_reproduces_scipy_plan(S, nsc, P, seed):
     assert np.max(np.abs(A - B)) < 2e-7                                  # float32 rounding of the stored host weights
     tri = ip.triangulations_parallel([pil, pil], S, nsc, workers=2)
     assert np.array_equal(tri[0], simp) and np.array_equal(tri[1], simp)
+
+
+def test_triangulation_iterator_equals_parallel_list():
+    rs = np.random.RandomState(7)
+    pils = [np.sort(rs.permutation(14 * 71)[:50 + 5 * i]) for i in range(9)]
+    want = ip.triangulations_parallel(pils, 14, 71, workers=0)
+    for w in (0, 3):
+        got = list(ip.triangulations_iter(pils, 14, 71, workers=w))
+        assert len(got) == len(want) and all(np.array_equal(a, b) for a, b in zip(got, want))
