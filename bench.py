@@ -181,6 +181,7 @@ def main():
     # est-MSE is evaluate_estimator's job, not part of the LS+MMSE step: one extra UNTIMED launch with the fused
     # error-sum output gives the numbers reported under "est_mse".
     mse_out = eng.run_frames(d_dev, seed=2024, frame_offset=rank * F, outputs=("metrics",))["metrics"].double()
+    summ = torch.stack([mse_out[:, 0].sum(), mse_out[:, 1].sum(), mse_out[:, 2].sum(), mse_out[:, 6].sum()])   # this rank's partial sums
     for i in range(args.warmup):
         step(i)
     if world > 1:
@@ -194,9 +195,6 @@ def main():
         step(args.warmup + i)
         ev[i][1].record()
     # the job's single collective: per-rank metric sums to every rank (RCCL over xGMI)
-    summ = torch.zeros(4, dtype=torch.float64, device=eng.device)
-    m = mse_out
-    summ[0], summ[1], summ[2], summ[3] = m[:, 0].sum(), m[:, 1].sum(), m[:, 2].sum(), m[:, 6].sum()
     if world > 1:
         summ_c = summ.to(coll_dev)
         gathered = [torch.zeros_like(summ_c) for _ in range(world)]
