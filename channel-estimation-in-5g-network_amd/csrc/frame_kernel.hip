@@ -222,6 +222,7 @@ struct FrameArgs {
     float2* hp;        // LDS [Pmax*R] LS estimates at the pilots
     float* red;
     float* alpha;
+    float2* psl;       // LDS [Pmax] pilot symbols in pilot order, written out linearly after phase W
     int tw_stride;     // float2 elements per tap row (even)
     RngKey key;
     int b;
@@ -297,9 +298,9 @@ __device__ __forceinline__ void frame_body(const FrameArgs& A, int nch) {
                 }
             }
             const bool p0 = lane < 63 && k0 < nsc && s0 < (unsigned)P, p1 = lane < 63 && k0 + 1 < nsc && s1 < (unsigned)P;
-            if (psb != nullptr) {
-                if (p0) psb[s0] = x0;
-                if (p1) psb[s1] = x1;
+            if (psb != nullptr) {                 // staged in LDS: 838 scattered 8-B global stores per frame cost more than their bytes
+                if (p0) A.psl[s0] = x0;
+                if (p1) A.psl[s1] = x1;
             }
             float4 w[NT];                                                        // twiddles of the pair, all taps
 #pragma unroll
@@ -345,8 +346,16 @@ __device__ __forceinline__ void frame_body(const FrameArgs& A, int nch) {
     }
     const bool want_metrics = out.metrics != nullptr;
     const bool want_est = (Lb != nullptr) || (Mb != nullptr) || want_metrics;
-    if (!want_est && out.h_ls_pilots == nullptr) return;
+    if (!want_est && out.h_ls_pilots == nullptr && psb == nullptr) return;
     __syncthreads();
+    if (psb != nullptr) {                             // pilot symbols: one linear write, 16 B per lane where the row is aligned
+        if ((((uintptr_t)psb) & 15) == 0) {
+            for (int i = tid * 2; i + 1 < P; i += blockDim.x * 2) st16(psb + i, A.psl[i], A.psl[i + 1]);
+            if ((P & 1) && tid == 0) st8(psb + P - 1, A.psl[P - 1]);
+        } else {
+            for (int i = tid; i < P; i += blockDim.x) st8(psb + i, A.psl[i]);
+        }
+    }
     if (out.h_ls_pilots != nullptr) {                // LS estimates at the pilots, [R][stride] per frame, zero padded
         float2* __restrict__ hl = (float2*)out.h_ls_pilots + (size_t)b * R * out.h_ls_stride;
         for (int i = tid; i < R * out.h_ls_stride; i += blockDim.x) {
@@ -482,23 +491,25 @@ frame_kernel(const FrameParams* __restrict__ fpp, const chest_frame_desc* __rest
     if (want_est && pat.plan == nullptr) { if (tid == 0) atomicExch(status, 2); return; }
     const int P = pat.P;
 
-    // ---- pilot mask: 4 resource elements per thread, one 32-bit store ---------------------------------
+    // ---- pilot mask: 16 resource elements per thread and one 16-B store, after peeling the row to 16-B alignment
+    //      (G is rarely a multiple of 16, so most rows start misaligned) ---------------------------------------------
     if (out.pilot_mask != nullptr) {
         uint8_t* mrow = out.pilot_mask + (size_t)b * G;
-        if ((((size_t)b * G) & 3) == 0) {
-            for (int g4 = tid * 4; g4 < G; g4 += blockDim.x * 4) {
-                if (g4 + 3 < G) {
-                    uint32_t v = 0;
+        const int lead = min(G, (int)((16 - ((uintptr_t)mrow & 15)) & 15));
+        const int nvec = (G - lead) >> 4, tail0 = lead + (nvec << 4);
+        if (tid < lead) mrow[tid] = pat.slot[tid] < P ? 1 : 0;
+        for (int v = tid; v < nvec; v += blockDim.x) {
+            const uint16_t* sp = pat.slot + lead + (v << 4);
+            uint32_t w[4];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) v |= (pat.slot[g4 + j] < P ? 1u : 0u) << (8 * j);
-                    *(uint32_t*)(mrow + g4) = v;
-                } else {
-                    for (int g = g4; g < G; ++g) mrow[g] = pat.slot[g] < P ? 1 : 0;
-                }
+            for (int q = 0; q < 4; ++q) {
+                w[q] = 0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) w[q] |= (sp[4 * q + j] < P ? 1u : 0u) << (8 * j);
             }
-        } else {
-            for (int g = tid; g < G; g += blockDim.x) mrow[g] = pat.slot[g] < P ? 1 : 0;
+            *(uint4*)(mrow + lead + (v << 4)) = make_uint4(w[0], w[1], w[2], w[3]);
         }
+        if (tid < G - tail0) mrow[tail0 + tid] = pat.slot[tail0 + tid] < P ? 1 : 0;
     }
 
     FrameArgs A;
@@ -511,6 +522,7 @@ frame_kernel(const FrameParams* __restrict__ fpp, const chest_frame_desc* __rest
     A.hp = A.tw + (size_t)KT * A.tw_stride;                      // [Pmax*R]
     A.red = (float*)(A.hp + (size_t)Pmax * R);                   // [32]
     A.alpha = A.red + 32;                                        // [8]
+    A.psl = (float2*)(A.alpha + 8);                              // [Pmax]
     const uint64_t frame = frame_offset + (uint64_t)b;
     A.key = RngKey{(uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)frame, (uint32_t)(frame >> 32)};
     A.b = b;
@@ -529,7 +541,7 @@ size_t frames_workspace_bytes(const chest_ctx* ctx, int64_t B) {
 }
 
 static size_t k2_lds_bytes(int nch, int Pmax, int R) {
-    return ((size_t)KT * frame_tw_stride(nch) + (size_t)Pmax * R) * sizeof(float2) + 40 * sizeof(float);
+    return ((size_t)KT * frame_tw_stride(nch) + (size_t)Pmax * R + (size_t)Pmax) * sizeof(float2) + 40 * sizeof(float);   // tw | hp | red, alpha | psl
 }
 
 static int launch_k2(chest_ctx* ctx, hipStream_t st, int32_t B, int nch, const chest_frame_desc* descs, int Pmax,
