@@ -62,3 +62,20 @@ def gather_records(local: "np.ndarray", group=None):
     parts = [torch.zeros_like(pad) for _ in range(world)]
     dist.all_gather(parts, pad, group=group)
     return torch.cat([p[:c] for p, c in zip(parts, counts)]).cpu().numpy()
+
+
+def broadcast_from_root(t, src: int = 0, group=None):
+    """Config 5's start-up exchange: the MMSE filter W (P x P complex64, 22.5 MB at P = 1 678) is prepared once
+    on ``src`` and broadcast to every rank; after that the ranks never talk until the final gather.  ``t`` is the tensor
+    on ``src`` and an equally shaped, equally typed buffer elsewhere; complex tensors travel as their real view (RCCL
+    has no complex type).  Returns ``t``.  No-op without an initialised process group."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return t
+    buf = torch.view_as_real(t) if t.is_complex() else t
+    if not buf.is_contiguous():
+        raise ValueError("broadcast_from_root needs a contiguous tensor")
+    dist.broadcast(buf, src=src, group=group)
+    return t
+

@@ -40,8 +40,16 @@ def _worker(rank, world, port, total, q):
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
     b, e = S_.shard_range(total, rank, world)
     allrec = S_.gather_records(_records(b, e))
+    import torch
+    W = torch.zeros(5, 5, dtype=torch.complex64)                 # config 5's start-up broadcast of the MMSE filter
     if rank == 0:
-        q.put(allrec)
+        W = (torch.arange(25, dtype=torch.float32).reshape(5, 5) * (1 + 2j)).to(torch.complex64)
+    S_.broadcast_from_root(W, src=0)
+    ok = bool(torch.equal(W, (torch.arange(25, dtype=torch.float32).reshape(5, 5) * (1 + 2j)).to(torch.complex64)))
+    oks = [None] * world
+    dist.all_gather_object(oks, ok)
+    if rank == 0:
+        q.put((allrec, all(oks)))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -57,7 +65,8 @@ def test_two_rank_gloo_gather_equals_single_process():
     procs = [ctx.Process(target=_worker, args=(r, world, port, total, q)) for r in range(world)]
     for p in procs:
         p.start()
-    got = q.get(timeout=300)
+    got, w_ok = q.get(timeout=300)
+    assert w_ok, "broadcast_from_root did not deliver W to every rank"
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
