@@ -22,6 +22,8 @@ def main():
     ap.add_argument("var")
     ap.add_argument("--value", default="1", help="value the variable is set to")
     ap.add_argument("--outputs", default="", help="comma-separated output subset (default: all seven)")
+    ap.add_argument("--place", choices=["none", "best", "worst"], default="none",
+                    help="which of 16 probed output placements to run on (default: the first allocation)")
     ap.add_argument("--rounds", type=int, default=30)
     ap.add_argument("--frames", type=int, default=10000)
     args = ap.parse_args()
@@ -41,6 +43,25 @@ def main():
     d_dev = torch.from_numpy(descs.view(np.uint8).copy()).to(eng.device)
     names = args.outputs.split(",") if args.outputs else ["tx", "rx", "H", "H_ls", "H_mmse", "pilot_symbols", "pilot_mask"]
     out = eng.run_frames(d_dev, seed=1, outputs=names)
+    if args.place != "none":
+        # probe 4 x 4 placements like Engine.place_outputs, but keep the requested extreme
+        g0 = [n for n in names if n in E.Engine.PLACEMENT_GROUPS[0]]
+        g1 = [n for n in names if n in E.Engine.PLACEMENT_GROUPS[1]]
+        c0 = [eng.run_frames(d_dev, seed=1, outputs=g0) for _ in range(4)]
+        c1 = [eng.run_frames(d_dev, seed=1, outputs=g1) if g1 else {} for _ in range(4)]
+        tm = {}
+        for i, a in enumerate(c0):
+            for j, b in enumerate(c1):
+                o = {**a, **b}
+                ts = []
+                for _ in range(3):
+                    eng.profile_begin(1)
+                    eng.run_frames(d_dev, seed=1, outputs=names, out=o, check=False)
+                    ts.append(eng.profile_read()[1])
+                tm[(i, j)] = float(np.median(ts[1:]))
+        pick = (min if args.place == "best" else max)(tm, key=tm.get)
+        out = {**c0[pick[0]], **c1[pick[1]]}
+        print(f"placement {args.place}: {tm[pick]:.3f} ms (range {min(tm.values()):.3f} .. {max(tm.values()):.3f})")
     res = {0: [], 1: []}
     for i in range(args.rounds * 2 + 4):
         setting = i & 1
