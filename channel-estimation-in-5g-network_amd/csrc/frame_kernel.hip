@@ -270,17 +270,30 @@ __device__ __forceinline__ void frame_body(const FrameArgs& A, int nch) {
 
     // ---- phase W: wave <-> symbol; per 126-subcarrier chunk: tx rows, then per rx antenna the H rows and the rx row.
     //      The wave's stores walk a handful of short sequential streams inside its own symbol slice.
-    for (int s = wave; s < S; s += nwave) {
-        unsigned k0 = 2u * lane;
-        unsigned kc0 = k0 < nsc ? k0 : nsc - 1, kc1 = k0 + 1 < nsc ? k0 + 1 : nsc - 1;
-        const uint16_t* __restrict__ srow = slots + (unsigned)s * nsc;
-        uint32_t sl0 = srow[kc0], sl1 = srow[kc1];                               // prefetched one chunk ahead
-        for (int j = 0; j < nch; ++j) {
+    // Work unit = (symbol, chunk); each wave takes a contiguous range of the S * nch units, i.e. whole symbols plus at most
+    // two partial ones, so any number of waves per workgroup is evenly loaded (8 waves: 8.75 units each for S = 14, nch = 5).
+    const int units = S * nch;
+    const int u_lo = (int)((long long)wave * units / nwave), u_hi = (int)((long long)(wave + 1) * units / nwave);
+    {
+        uint32_t sl0 = 0, sl1 = 0;
+        if (u_lo < u_hi) {                                                       // slots of the first unit
+            const int s_ = u_lo / nch, j_ = u_lo - s_ * nch;
+            const unsigned k_ = 2u * lane + 126u * (unsigned)j_;
+            const uint16_t* __restrict__ sr_ = slots + (unsigned)s_ * nsc;
+            sl0 = sr_[k_ < nsc ? k_ : nsc - 1]; sl1 = sr_[k_ + 1 < nsc ? k_ + 1 : nsc - 1];
+        }
+        for (int u = u_lo; u < u_hi; ++u) {
+            const int s = u / nch, j = u - s * nch;
+            const unsigned k0 = 2u * lane + 126u * (unsigned)j;
+            const unsigned kc0 = k0 < nsc ? k0 : nsc - 1, kc1 = k0 + 1 < nsc ? k0 + 1 : nsc - 1;
             const RowGeom g{k0, nsc, lane < 63, j == 0 && lane == 0};
             const unsigned s0 = sl0, s1 = sl1;
-            const unsigned kn = k0 + 126;
-            const unsigned kn0 = kn < nsc ? kn : nsc - 1, kn1 = kn + 1 < nsc ? kn + 1 : nsc - 1;
-            if (j + 1 < nch) { sl0 = srow[kn0]; sl1 = srow[kn1]; }
+            if (u + 1 < u_hi) {                                                  // prefetched one unit ahead
+                const int sn = (u + 1) / nch, jn = (u + 1) - sn * nch;
+                const unsigned kn = 2u * lane + 126u * (unsigned)jn;
+                const uint16_t* __restrict__ srn = slots + (unsigned)sn * nsc;
+                sl0 = srn[kn < nsc ? kn : nsc - 1]; sl1 = srn[kn + 1 < nsc ? kn + 1 : nsc - 1];
+            }
             float u0, u1;
             if (usym != nullptr) {
                 u0 = usym[s0]; u1 = usym[s1];
@@ -341,7 +354,6 @@ __device__ __forceinline__ void frame_body(const FrameArgs& A, int nch) {
                 if (p0) hp[s0 * R + r] = pilot_divide(r0, x0);                   // (src/baseline_estimators.py:110)
                 if (p1) hp[s1 * R + r] = pilot_divide(r1, x1);
             }
-            k0 = kn; kc0 = kn0; kc1 = kn1;
         }
     }
     const bool want_metrics = out.metrics != nullptr;
@@ -382,17 +394,25 @@ __device__ __forceinline__ void frame_body(const FrameArgs& A, int nch) {
     const PlanRec* __restrict__ plan = (const PlanRec*)pat.plan;
     const float invT = 1.0f / (float)T;
     float m_ls = 0.f, m_mm = 0.f;
-    for (int s = wave; s < S; s += nwave) {
-        unsigned k0 = 2u * lane;
-        unsigned kc0 = k0 < nsc ? k0 : nsc - 1, kc1 = k0 + 1 < nsc ? k0 + 1 : nsc - 1;
-        const PlanRec* __restrict__ prow = plan + (unsigned)s * nsc;
-        PlanRec q0 = prow[kc0], q1 = prow[kc1];                                  // prefetched one chunk ahead
-        for (int j = 0; j < nch; ++j) {
+    {
+        PlanRec q0{0.f, 0.f, 0u, 0u}, q1{0.f, 0.f, 0u, 0u};
+        if (u_lo < u_hi) {
+            const int s_ = u_lo / nch, j_ = u_lo - s_ * nch;
+            const unsigned k_ = 2u * lane + 126u * (unsigned)j_;
+            const PlanRec* __restrict__ pr_ = plan + (unsigned)s_ * nsc;
+            q0 = pr_[k_ < nsc ? k_ : nsc - 1]; q1 = pr_[k_ + 1 < nsc ? k_ + 1 : nsc - 1];
+        }
+        for (int u = u_lo; u < u_hi; ++u) {
+            const int s = u / nch, j = u - s * nch;
+            const unsigned k0 = 2u * lane + 126u * (unsigned)j;
             const RowGeom g{k0, nsc, lane < 63, j == 0 && lane == 0};
             const PlanRec c0 = q0, c1 = q1;
-            const unsigned kn = k0 + 126;
-            const unsigned kn0 = kn < nsc ? kn : nsc - 1, kn1 = kn + 1 < nsc ? kn + 1 : nsc - 1;
-            if (j + 1 < nch) { q0 = prow[kn0]; q1 = prow[kn1]; }
+            if (u + 1 < u_hi) {                                                  // prefetched one unit ahead
+                const int sn = (u + 1) / nch, jn = (u + 1) - sn * nch;
+                const unsigned kn = 2u * lane + 126u * (unsigned)jn;
+                const PlanRec* __restrict__ prn = plan + (unsigned)sn * nsc;
+                q0 = prn[kn < nsc ? kn : nsc - 1]; q1 = prn[kn + 1 < nsc ? kn + 1 : nsc - 1];
+            }
             for (int r = 0; r < R; ++r) {
                 const float2 e0 = interp(c0, hp, R, r), e1 = interp(c1, hp, R, r);
                 const float2 en = from_next_lane(e0);
@@ -429,7 +449,6 @@ __device__ __forceinline__ void frame_body(const FrameArgs& A, int nch) {
                     }
                 }
             }
-            k0 = kn; kc0 = kn0; kc1 = kn1;
         }
     }
     if (want_metrics) {
