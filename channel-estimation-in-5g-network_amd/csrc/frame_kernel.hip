@@ -312,8 +312,8 @@ __device__ __forceinline__ void frame_body(const FrameArgs& A, int nch) {
             }
             const bool p0 = lane < 63 && k0 < nsc && s0 < (unsigned)P, p1 = lane < 63 && k0 + 1 < nsc && s1 < (unsigned)P;
             if (psb != nullptr) {                 // staged in LDS: 838 scattered 8-B global stores per frame cost more than their bytes
-                if (p0) A.psl[s0] = x0;
-                if (p1) A.psl[s1] = x1;
+                if (A.psl != nullptr) { if (p0) A.psl[s0] = x0; if (p1) A.psl[s1] = x1; }
+                else { if (p0) psb[s0] = x0; if (p1) psb[s1] = x1; }
             }
             float4 w[NT];                                                        // twiddles of the pair, all taps
 #pragma unroll
@@ -360,7 +360,7 @@ __device__ __forceinline__ void frame_body(const FrameArgs& A, int nch) {
     const bool want_est = (Lb != nullptr) || (Mb != nullptr) || want_metrics;
     if (!want_est && out.h_ls_pilots == nullptr && psb == nullptr) return;
     __syncthreads();
-    if (psb != nullptr) {                             // pilot symbols: one linear write, 16 B per lane where the row is aligned
+    if (psb != nullptr && A.psl != nullptr) {         // pilot symbols: one linear write, 16 B per lane where the row is aligned
         if ((((uintptr_t)psb) & 15) == 0) {
             for (int i = tid * 2; i + 1 < P; i += blockDim.x * 2) st16(psb + i, A.psl[i], A.psl[i + 1]);
             if ((P & 1) && tid == 0) st8(psb + P - 1, A.psl[P - 1]);
@@ -478,7 +478,7 @@ __global__ void __launch_bounds__(CHEST_K2_BOUNDS, CHEST_K2_MINWAVES)
 frame_kernel(const FrameParams* __restrict__ fpp, const chest_frame_desc* __restrict__ descs,
              const PatternDev* __restrict__ patterns, int Pmax, uint64_t seed, uint64_t frame_offset,
              const chest_injected inj, const chest_frame_outputs out, const float* __restrict__ state,
-             int nch, int xcd_remap, int* __restrict__ status) {
+             int nch, int xcd_remap, int* __restrict__ status, int stage_pilots) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const FrameParams& fp = *fpp;
     const int tid = threadIdx.x;
@@ -541,7 +541,7 @@ frame_kernel(const FrameParams* __restrict__ fpp, const chest_frame_desc* __rest
     A.hp = A.tw + (size_t)KT * A.tw_stride;                      // [Pmax*R]
     A.red = (float*)(A.hp + (size_t)Pmax * R);                   // [32]
     A.alpha = A.red + 32;                                        // [8]
-    A.psl = (float2*)(A.alpha + 8);                              // [Pmax]
+    A.psl = stage_pilots ? (float2*)(A.alpha + 8) : nullptr;     // [Pmax], or pilot symbols go straight to global memory
     const uint64_t frame = frame_offset + (uint64_t)b;
     A.key = RngKey{(uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)frame, (uint32_t)(frame >> 32)};
     A.b = b;
@@ -559,20 +559,24 @@ size_t frames_workspace_bytes(const chest_ctx* ctx, int64_t B) {
     return (size_t)B * frame_state_floats(ctx->fp.S, ctx->fp.R, ctx->fp.T) * sizeof(float);
 }
 
-static size_t k2_lds_bytes(int nch, int Pmax, int R) {
-    return ((size_t)KT * frame_tw_stride(nch) + (size_t)Pmax * R + (size_t)Pmax) * sizeof(float2) + 40 * sizeof(float);   // tw | hp | red, alpha | psl
+static size_t k2_lds_bytes(int nch, int Pmax, int R, bool stage_pilots) {
+    return ((size_t)KT * frame_tw_stride(nch) + (size_t)Pmax * R + (stage_pilots ? (size_t)Pmax : 0)) * sizeof(float2) +
+           40 * sizeof(float);                                   // tw | hp | red, alpha | psl
 }
 
 static int launch_k2(chest_ctx* ctx, hipStream_t st, int32_t B, int nch, const chest_frame_desc* descs, int Pmax,
                      uint64_t seed, uint64_t frame_offset, const chest_injected& inj, const chest_frame_outputs& out,
                      const float* workspace) {
-    size_t lds2 = k2_lds_bytes(nch, Pmax, ctx->fp.R);
+    // Pilot symbols are staged in LDS unless that costs a resident workgroup (80 KiB each for two per CU) or does not fit.
+    const size_t with = k2_lds_bytes(nch, Pmax, ctx->fp.R, true), without = k2_lds_bytes(nch, Pmax, ctx->fp.R, false);
+    const bool stage = with <= 160 * 1024 && !(with > 80 * 1024 && without <= 80 * 1024);
+    size_t lds2 = stage ? with : without;
     if (const char* pad = getenv("CHEST_K2_LDS_PAD")) lds2 += (size_t)atol(pad);      // experiment: lower the occupancy
     if (lds2 > 160 * 1024) { set_error("frame kernel needs %zu B of LDS (> 160 KiB): too many antennas or pilots", lds2); return CHEST_EINVAL; }
     CHEST_LDS_OPT_IN(ctx, LDS_FRAME, frame_kernel, lds2);
     hipLaunchKernelGGL(frame_kernel, dim3(B), dim3(ctx->block_threads), lds2, st, ctx->d_fp, descs, ctx->d_patterns,
                        Pmax, seed, frame_offset, inj, out, workspace, nch, getenv("CHEST_NO_XCD_REMAP") ? 0 : (getenv("CHEST_FRAME_STRIDE") ? -atoi(getenv("CHEST_FRAME_STRIDE")) : (getenv("CHEST_XCD_BLOCK") ? atoi(getenv("CHEST_XCD_BLOCK")) : 1)),
-                       ctx->d_status);
+                       ctx->d_status, stage ? 1 : 0);
     return CHEST_OK;
 }
 

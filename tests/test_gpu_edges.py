@@ -236,3 +236,9 @@ def test_place_outputs_returns_usable_buffers():
         assert out[n].shape == ref[n].shape and torch.equal(out[n], ref[n]), n
     only, rep1 = eng.place_outputs(descs, ["H_ls"], seed=5, tries=1)
     assert list(only) == ["H_ls"] and rep1["combinations"] == 1
+
+
+def test_many_pilots_fall_back_to_direct_pilot_symbol_stores():
+    """4x4 / 2048-FFT with 12 % pilots (P = 2 014): staging the pilot symbols in LDS would need 171 KB, so the frame kernel
+    writes them straight to global memory instead (155 KB); all outputs still match the oracle."""
+    _check_native(E.Geometry(fft_size=2048, cp_length=144, useful_subcarriers=1200, num_tx=4, num_rx=4), "EVA", 100.0, 10.0, 0.12, B=1)
