@@ -63,6 +63,7 @@ def main():
         out = {**c0[pick[0]], **c1[pick[1]]}
         print(f"placement {args.place}: {tm[pick]:.3f} ms (range {min(tm.values()):.3f} .. {max(tm.values()):.3f})")
     res = {0: [], 1: []}
+    taps = {}
     for i in range(args.rounds * 2 + 4):
         setting = i & 1
         if setting:
@@ -71,11 +72,13 @@ def main():
             os.environ.pop(args.var, None)
         eng.profile_begin(1)
         eng.run_frames(d_dev, seed=1, frame_offset=i * F, outputs=names, out=out, check=False)
-        _, k_ms, _ = eng.profile_read()
+        t_ms, k_ms, _ = eng.profile_read()
         if i >= 4:
             res[setting].append(k_ms)
+            taps.setdefault(setting, []).append(t_ms)
     os.environ.pop(args.var, None)
     a, b = np.array(res[0]), np.array(res[1])
+    print(f"taps_kernel: unset {np.mean(taps[0]):.4f} ms, set {np.mean(taps[1]):.4f} ms")
     print(f"{args.var} unset: frame_kernel {a.mean():.4f} ms (min {a.min():.4f}, sd {a.std():.4f});  "
           f"set: {b.mean():.4f} ms (min {b.min():.4f}, sd {b.std():.4f});  unset/set = {a.mean() / b.mean():.4f}")
 
