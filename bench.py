@@ -52,17 +52,19 @@ def cpu_baseline(workload, budget_s=20.0):
     cores = min(os.cpu_count() or 1, 16)
     # one frame costs ~0.5-1 s per core in faithful mode; scale the sample to ~budget_s of wall time
     t0 = time.time()
-    _cpu_frames((workload, 1, 12345))
+    _cpu_frames((workload, 1, 12345))                         # one frame to size the sample
     one = time.time() - t0
     per_proc = max(1, int(budget_s / max(one, 1e-3)))
     per_proc = min(per_proc, 32)
     ctx = mp.get_context("spawn")
     t0 = time.time()
     with ctx.Pool(cores) as pool:
-        pool.map(_cpu_frames, [(workload, per_proc, 1000 + i) for i in range(cores)])
+        parts = pool.map(_cpu_frames, [(workload, per_proc, 1000 + i) for i in range(cores)])
     dt = time.time() - t0
     frames = per_proc * cores
+    mse_ls = float(np.mean([p[1] for p in parts])); mse_mm = float(np.mean([p[2] for p in parts]))
     return {"value": frames / dt, "unit": "frames/s", "cores": cores, "kind": "port",
+            "est_mse": {"ls": mse_ls, "mmse": mse_mm, "frames": frames},        # same statistic as the GPU line's est_mse, other random frames
             "sample": f"{frames} frames of {workload} ({per_proc}/process x {cores} processes), oracle faithful mode "
                       f"(float64 NumPy/SciPy restatement with the reference's cost structure), {dt:.1f} s wall"}
 
@@ -81,6 +83,7 @@ def _cpu_frames(args):
     nsc = len(O.used_indices(N, U))
     L = len(O.PROFILES[ct][0])
     rs = np.random.RandomState(seed)
+    acc_ls = acc_mm = 0.0
     for _ in range(n):
         d = O.legacy_frame_draws(rs, S, nsc, T, R, L, dens)
         pos, mask = O.pattern_from_indices(d["pilot_indices"], S, nsc)
@@ -92,9 +95,10 @@ def _cpu_frames(args):
         rx4 = O.repeat_over_tx(rx, T)
         ls = O.ls_estimate(rx4, pil, mask, pos, "linear")
         mm = O.mmse_estimate(rx4, pil, mask, pos, snr, dense=True)
-        O.evaluate_estimator(H, ls), O.evaluate_estimator(H, mm)
+        acc_ls += O.evaluate_estimator(H, ls)["mse"]
+        acc_mm += O.evaluate_estimator(H, mm)["mse"]
     del limiter
-    return n
+    return n, acc_ls / n, acc_mm / n
 
 
 def main():
