@@ -430,7 +430,7 @@ class Engine:
         torch.cuda.current_stream(self.device).synchronize()       # scratch is freed on return
         return out
 
-    def mmse_full_apply_pilots(self, h_ls_pilots, slot, W):
+    def mmse_full_apply_pilots(self, h_ls_pilots, slot, W, out=None, scratch=None):
         """Full-covariance MMSE for frames produced by ``run_frames(..., outputs=[..., "h_ls_pilots"])``: one right-hand
         side per (frame, rx) instead of per (frame, rx, tx) -- the reference's callers repeat rx over tx, so the T grids of
         an rx antenna are identical -- and every result written T times.  Returns H_mmse [B,S,R,T,nsc]."""
@@ -442,13 +442,28 @@ class Engine:
         if tuple(W.shape) != (P, P):
             raise ValueError(f"W must be [{P}, {P}] for this pattern")
         B = h.shape[0]
-        scratch = torch.empty(N.lib().chest_mmse_full_apply_scratch_bytes(P, B * g.num_rx), dtype=torch.uint8, device=self.device)
-        out = self.empty_c64(B, g.num_symbols, g.num_rx, g.num_tx, g.num_sc)
+        need = N.lib().chest_mmse_full_apply_scratch_bytes(P, B * g.num_rx)
+        own_scratch = scratch is None
+        if own_scratch:
+            scratch = torch.empty(need, dtype=torch.uint8, device=self.device)
+        elif scratch.numel() * scratch.element_size() < need:
+            raise ValueError(f"scratch holds {scratch.numel() * scratch.element_size()} B, {need} B needed")
+        shape = (B, g.num_symbols, g.num_rx, g.num_tx, g.num_sc)
+        if out is None:
+            out = self.empty_c64(*shape)
+        elif tuple(out.shape) != shape or out.dtype != torch.complex64 or not out.is_contiguous():
+            raise ValueError("out must be a contiguous complex64 [B,S,R,T,nsc] tensor")
         N.check(N.lib().chest_mmse_full_apply_pilots(self._h, self._stream(), B, h.data_ptr(), h.shape[2], int(slot),
                                                      W.contiguous().data_ptr(), scratch.data_ptr(), out.data_ptr()),
                 "chest_mmse_full_apply_pilots")
-        torch.cuda.current_stream(self.device).synchronize()       # scratch is freed on return
+        if own_scratch:
+            torch.cuda.current_stream(self.device).synchronize()   # our scratch is freed on return
         return out
+
+    def mmse_full_scratch(self, slot, num_grids):
+        """Reusable scratch tensor for mmse_full_apply(_pilots) on ``num_grids`` right-hand sides of this pattern."""
+        return torch.empty(N.lib().chest_mmse_full_apply_scratch_bytes(self.num_pilots(slot), int(num_grids)), dtype=torch.uint8,
+                           device=self.device)
 
     def cubic_operator(self, pilot_idx):
         """Device copy of the dense Clough-Tocher operator of a pattern (cached, least recently used of 4 dropped)."""
