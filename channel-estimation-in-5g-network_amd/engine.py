@@ -406,7 +406,7 @@ class Engine:
         torch.cuda.current_stream(self.device).synchronize()       # ws is freed on return
         return W
 
-    def mmse_full_apply(self, rx4d, tx_pilots, slot, W):
+    def mmse_full_apply(self, rx4d, tx_pilots, slot, W, out=None, scratch=None):
         g = self.geom
         rx = self._c64(rx4d)
         if rx.dim() == 4:
@@ -422,12 +422,21 @@ class Engine:
         if tp.numel() != (P if tp.dim() == 1 else B * P):
             raise ValueError("tx_pilots does not match the pattern's pilot count")
         M = B * g.num_rx * g.num_tx
-        scratch = torch.empty(N.lib().chest_mmse_full_apply_scratch_bytes(P, M), dtype=torch.uint8, device=self.device)
-        out = torch.empty_like(rx)
+        need = N.lib().chest_mmse_full_apply_scratch_bytes(P, M)
+        own_scratch = scratch is None
+        if own_scratch:
+            scratch = torch.empty(need, dtype=torch.uint8, device=self.device)
+        elif scratch.numel() * scratch.element_size() < need:
+            raise ValueError(f"scratch holds {scratch.numel() * scratch.element_size()} B, {need} B needed")
+        if out is None:
+            out = torch.empty_like(rx)
+        elif tuple(out.shape) != tuple(rx.shape) or out.dtype != torch.complex64 or not out.is_contiguous():
+            raise ValueError("out must be a contiguous complex64 tensor shaped like rx_symbols")
         N.check(N.lib().chest_mmse_full_apply(self._h, self._stream(), B, rx.data_ptr(), tp.data_ptr(), stride, int(slot),
                                               W.contiguous().data_ptr(), scratch.data_ptr(), out.data_ptr()),
                 "chest_mmse_full_apply")
-        torch.cuda.current_stream(self.device).synchronize()       # scratch is freed on return
+        if own_scratch:
+            torch.cuda.current_stream(self.device).synchronize()   # our scratch is freed on return
         return out
 
     def mmse_full_apply_pilots(self, h_ls_pilots, slot, W, out=None, scratch=None):
