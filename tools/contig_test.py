@@ -53,16 +53,19 @@ for i in range(5):
     sets.append(("torch", eng.run_frames(d_dev, seed=1, outputs=names)))
     o = {k: (ext_like(v) if k in ("tx", "rx", "H", "H_ls", "H_mmse") else torch.zeros_like(v)) for k, v in ref.items()}
     sets.append(("contig", o))
-res = {i: [] for i in range(len(sets))}
-for it in range(8):
+subsets = {"all": names, "tx rx H": ["tx", "rx", "H"], "H_ls H_mmse": ["H_ls", "H_mmse"], "H": ["H"], "rx": ["rx"]}
+res = {}
+for it in range(6):
     for i, (kind, o) in enumerate(sets):
-        eng.profile_begin(1)
-        eng.run_frames(d_dev, seed=1, outputs=names, out=o, check=False)
-        k = eng.profile_read()[1]
-        if it >= 2:
-            res[i].append(k)
+        for sn, sub in subsets.items():
+            eng.profile_begin(1)
+            eng.run_frames(d_dev, seed=1, outputs=sub, out={k: o[k] for k in sub}, check=False)
+            k = eng.profile_read()[1]
+            if it >= 2:
+                res.setdefault((i, sn), []).append(k)
 eng.run_frames(d_dev, seed=1, outputs=names, out=sets[1][1])
 ok = all(torch.equal(sets[1][1][k], ref[k]) for k in names)
+print("set      " + "".join(f"{sn:>14s}" for sn in subsets))
 for i, (kind, o) in enumerate(sets):
-    print(f"{kind:7s} set {i // 2}: frame_kernel {np.mean(res[i]):.3f} ms")
+    print(f"{kind:7s}{i // 2} " + "".join(f"{np.mean(res[(i, sn)]):14.3f}" for sn in subsets))
 print("contiguous-backed outputs equal the torch-backed ones:", ok)
