@@ -214,3 +214,15 @@ def test_triangulation_iterator_equals_parallel_list():
     for w in (0, 3):
         got = list(ip.triangulations_iter(pils, 14, 71, workers=w))
         assert len(got) == len(want) and all(np.array_equal(a, b) for a, b in zip(got, want))
+
+
+def test_bench_algorithmic_bytes_match_the_survey_formula():
+    """bench.py's roofline numerator: 8*S*nsc*(T + R + R*T*(1 + n_est)) + S*nsc + 8*P (SURVEY 8d without the 4-B pilot
+    index, which belongs to the shared pattern here)."""
+    import bench
+    assert bench.algorithmic_bytes_per_frame(14, 599, 2, 2, 838, 2) == 1088498
+    assert bench.algorithmic_bytes_per_frame(14, 599, 4, 4, 838, 2) == 3772018
+    assert bench.algorithmic_bytes_per_frame(14, 599, 1, 1, 838, 2) == 350530
+    assert bench.algorithmic_bytes_per_frame(14, 599, 2, 2, 838, 2) + 4 * 838 == 1091850       # SURVEY's figure for config 2
+    assert set(bench.WORKLOADS) >= {"cfg2_2x2_eva_ls_mmse", "cfg3_4x4_etu_mmse", "cfg1_siso_epa_ls"}
+    assert bench.WORKLOADS["cfg2_2x2_eva_ls_mmse"][-1] == 10000 and bench.HBM_PEAK_GBS == 8000.0
