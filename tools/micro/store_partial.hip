@@ -38,7 +38,7 @@ __global__ void __launch_bounds__(448) frame(char* tx, char* rx, char* H, char* 
         }
 }
 int main() {
-    const size_t fT = (size_t)B * S * 2 * 4800, fH = (size_t)B * S * 4 * 4800;
+    const size_t fT = (size_t)B * S * 2 * 4864, fH = (size_t)B * S * 4 * 4864;
     hipEvent_t a, c; hipEventCreate(&a); hipEventCreate(&c);
     auto timeit = [&](auto f) { f(); hipDeviceSynchronize(); hipEventRecord(a); for (int i = 0; i < 6; ++i) f(); hipEventRecord(c); hipEventSynchronize(c); float ms; hipEventElapsedTime(&ms, a, c); return ms / 6; };
     for (int k = 0; k < 3; ++k) {
@@ -49,7 +49,8 @@ int main() {
             const float t_full = timeit([&] { frame<<<B, 448>>>(tx, rx, H, L, M, 4800, 64, delay); });
             const float t_part = timeit([&] { frame<<<B, 448>>>(tx, rx, H, L, M, 4792, 63, delay); });
             const float t_mix = timeit([&] { frame<<<B, 448>>>(tx, rx, H, L, M, 4800, 63, delay); });
-            printf("set %d delay %3d: 4800-B rows / 1024-B stores %6.3f ms | 4792-B rows / 1008-B stores %6.3f ms | 4800-B rows / 1008-B stores %6.3f ms\n", k, delay, t_full, t_part, t_mix);
+            const float t_pad = timeit([&] { frame<<<B, 448>>>(tx, rx, H, L, M, 4864, 64, delay); });
+            printf("set %d delay %3d: 4800-B rows / 1024-B stores %6.3f ms | 4792-B rows / 1008-B stores %6.3f ms | 4800-B rows / 1008-B stores %6.3f ms | 4864-B rows (38 lines) / 1024-B stores %6.3f ms\n", k, delay, t_full, t_part, t_mix, t_pad);
             fflush(stdout);
         }
     }
