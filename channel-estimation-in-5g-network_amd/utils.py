@@ -69,6 +69,8 @@ def awgn_noise(signal_shape: Tuple, snr_db: float, signal_power: float = 1.0) ->
 # ---- QPSK / 16-QAM (src/utils.py:71-153) ----------------------------------------------------------------------
 def qam_modulation(bits, M: int = 4):
     """Gray-mapped QPSK (M=4) or 16-QAM (M=16); other orders raise NotImplementedError (:104)."""
+    if M not in (4, 16):
+        raise NotImplementedError(f"Modulation order {M} not implemented")
     if isinstance(bits, torch.Tensor):
         return _eng().qam_modulate(bits, M)
     return _eng().qam_modulate(np.asarray(bits) != 0, M, wide=True).cpu().numpy()
@@ -77,6 +79,8 @@ def qam_modulation(bits, M: int = 4):
 def qam_demodulation(symbols, M: int = 4):
     """Minimum-distance demodulation -> flattened bits, MSB first (:139-153).  NumPy callers get the reference's
     ``int`` array and float64 decisions on their complex128 input."""
+    if M not in (4, 16):
+        raise NotImplementedError(f"Demodulation order {M} not implemented")
     if isinstance(symbols, torch.Tensor):
         return _eng().qam_demodulate(symbols, M)
     s = np.asarray(symbols)
