@@ -141,3 +141,18 @@ def test_qam_round_trip_and_error_count_at_scale(M):
     assert int(cnt.item()) == want
     ber = U.calculate_ber(bits, bad)
     assert float(ber) == 12345 / n
+
+
+def test_utils_error_measures_match_numpy():
+    """calculate_mse / calculate_nmse (src/utils.py:161-170) on the GPU's float64 error sums, NumPy and device inputs."""
+    import torch
+    rs = np.random.RandomState(12)
+    a = (rs.randn(3, 14, 2, 2, 599) + 1j * rs.randn(3, 14, 2, 2, 599))
+    b = a + 0.1 * (rs.randn(*a.shape) + 1j * rs.randn(*a.shape))
+    mse = np.mean(np.abs(a - b) ** 2)
+    nmse = mse / (np.mean(np.abs(a) ** 2) + 1e-12)
+    assert U.calculate_mse(a, b) == pytest.approx(mse, rel=2e-6)            # inputs travel as complex64
+    assert U.calculate_nmse(a, b) == pytest.approx(nmse, rel=2e-6)
+    ta, tb = torch.from_numpy(a.astype(np.complex64)).cuda(), torch.from_numpy(b.astype(np.complex64)).cuda()
+    assert float(U.calculate_nmse(ta, tb)) == pytest.approx(nmse, rel=2e-6)
+    assert torch.equal(U.real_to_complex(U.complex_to_real(ta)), ta)
