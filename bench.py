@@ -1,19 +1,27 @@
 #!/usr/bin/env python3
 """Throughput bench of the fused frame pipeline (simulate + LS + MMSE) on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--workload NAME]
 
-A "step" is one pass of the hot path over one batch of synthetic frames: BASELINE.json configs[1]
-(2x2 MIMO, 1024-FFT, EVA at 60 km/h = 111.1 Hz @ 2 GHz, SNR 10 dB, 10 % pilots, LS + MMSE, 10 000
-frames) per GPU.  Frames are independent, so N GPUs each run their own contiguous frame range
-(weak scaling, no data-path collective); one RCCL all_gather of the per-rank metric sums closes the
-job.  Rank 0 prints ONE JSON line.  Inputs (frame descriptors, pilot patterns, interpolation plans)
-are resident in HBM before the timed region; outputs are written to HBM and stay there.
+A "step" is one pass of the hot path over one batch of synthetic frames on every GPU.  Default workload: BASELINE.json
+configs[1] (2x2 MIMO, 1024-FFT, EVA at 60 km/h = 111.1 Hz @ 2 GHz, SNR 10 dB, 10 % pilots, LS + MMSE, 10 000 frames per
+GPU).  Other workloads (`--workload`): cfg1 / cfg3 shapes, `cfg4_dataset_mixed` (the dataset loop of
+src/dataset_generator.py:112-125: per-frame random channel type / Doppler / SNR / pilot density, LS + MMSE labels) and
+`cfg5_4x4_2048_fullcov` (4x4, 2048-FFT, ETU 300 km/h, full-covariance MMSE src/baseline_estimators.py:181-190 on the MFMA
+pipe).  Frames are independent, so N GPUs each run their own contiguous frame range (weak scaling, no data-path
+collective); one RCCL gather of the per-rank metric sums closes the job (cfg5 additionally broadcasts the prepared filter
+W once, before the timed region).  Rank 0 prints ONE JSON line.  Inputs (frame descriptors, pilot patterns, interpolation
+plans) are resident in HBM before the timed region; outputs are written to HBM and stay there.
+
+`--gpus N` with N > 1 and no launcher (WORLD_SIZE unset) starts the N ranks itself, one child process per GPU, BEFORE
+this process touches the GPU; under `python -m torch.distributed.run` the launcher's environment is used as is.
 """
 import argparse
 import importlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -25,37 +33,105 @@ if ROOT not in sys.path:
 PKG = "channel-estimation-in-5g-network_amd"
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 
 WORKLOADS = {
-    # name: (T, R, fft, cp, U, channel, doppler_hz, snr_db, density, frames_per_step)
-    "cfg2_2x2_eva_ls_mmse": (2, 2, 1024, 72, 600, "EVA", 111.1, 10.0, 0.10, 10000),
-    "cfg3_4x4_etu_mmse": (4, 4, 1024, 72, 600, "ETU", 370.4, 10.0, 0.10, 6250),
-    "cfg1_siso_epa_ls": (1, 1, 1024, 72, 600, "EPA", 5.56, 10.0, 0.10, 10000),
+    # kind "frames": one chest_frames_run per step, identical parameters for every frame
+    "cfg2_2x2_eva_ls_mmse": dict(kind="frames", T=2, R=2, N=1024, cp=72, U=600, ct="EVA", fd=111.1, snr=10.0, dens=0.10,
+                                 frames=10000),
+    "cfg3_4x4_etu_mmse": dict(kind="frames", T=4, R=4, N=1024, cp=72, U=600, ct="ETU", fd=370.4, snr=10.0, dens=0.10,
+                              frames=6250),
+    "cfg1_siso_epa_ls": dict(kind="frames", T=1, R=1, N=1024, cp=72, U=600, ct="EPA", fd=5.56, snr=10.0, dens=0.10,
+                             frames=10000),
+    # kind "dataset": per-frame uniform choice of type / Doppler / SNR / density (run_phase3_dataset_generation.py:104-107),
+    # frame i keyed by (seed 42, global index i); descriptors are generated on the host inside the timed step
+    "cfg4_dataset_mixed": dict(kind="dataset", T=2, R=2, N=1024, cp=72, U=600, frames=10000,
+                               types=("EPA", "EVA", "ETU"), dopplers=(10.0, 50.0, 100.0, 200.0),
+                               snrs=(-5.0, 0.0, 5.0, 10.0, 15.0, 20.0, 25.0, 30.0), densities=(0.05, 0.10)),
+    # kind "fullcov": simulate -> LS at the pilots -> W h_ls on the f32 MFMA pipe -> interpolation (one pattern, W prepared once)
+    "cfg5_4x4_2048_fullcov": dict(kind="fullcov", T=4, R=4, N=2048, cp=144, U=1200, ct="ETU", fd=555.6, snr=10.0, dens=0.10,
+                                  frames=2048),
 }
 PATTERN_GROUP = 1024           # frames that share one pilot pattern / interpolation plan (--pattern-group 1: one per frame)
 
 
-def algorithmic_bytes_per_frame(S, nsc, T, R, P, n_est=2):
-    """Compulsory HBM traffic of one frame when every output is written exactly once as complex64
-    (SURVEY 8d): tx + rx + H + n_est estimates, 1-B mask per RE, 8-B pilot symbol per pilot.
-    (SURVEY's figure adds a 4-B pilot index per pilot; here the index list belongs to the shared
-    pattern, so it is not counted per frame.)"""
-    return 8 * S * nsc * (T + R + R * T * (1 + n_est)) + S * nsc + 8 * P
+def algorithmic_bytes_per_frame(S, nsc, T, R, P, n_est=2, mask_bytes=1, pilot_bytes=8, extra=0):
+    """Compulsory HBM traffic of one frame when every output is written exactly once as complex64:
+    tx + rx + H + n_est estimates, the mask, the pilot symbols (8 B each; the 4-B pilot index of SURVEY's figure belongs
+    to the shared pattern here and is not counted per frame), plus `extra` bytes of per-frame records."""
+    return 8 * S * nsc * (T + R + R * T * (1 + n_est)) + mask_bytes * S * nsc + pilot_bytes * P + extra
 
 
+# =====================================================================================================
+# N ranks from a plain shell
+# =====================================================================================================
+def _free_port():
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def spawn_ranks(n, argv):
+    """Start `n` copies of this script, one per GPU, with the torchrun environment (RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_ADDR / MASTER_PORT).  The parent never initialises the GPU; rank 0's stdout is this process's stdout.
+    Returns the job's exit code: 0 only if every rank exited 0; the first failure terminates the remaining ranks."""
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        out = None if r == 0 else subprocess.DEVNULL            # one JSON line, from rank 0; stderr of every rank is kept
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env, stdout=out))
+    rc = 0
+    alive = set(range(n))
+    while alive:
+        for r in sorted(alive):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            alive.discard(r)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                print(f"bench.py: rank {r} exited with code {code}; stopping the other ranks", file=sys.stderr, flush=True)
+                for q in alive:
+                    procs[q].terminate()                        # exact PIDs we started
+        if alive:
+            time.sleep(0.05)
+    return rc
+
+
+def _selftest_spawn(world, rank):
+    """CPU-only rehearsal of the launch logic (tests/test_bench_spawn.py): gloo group, one all_reduce, one JSON line."""
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    t = torch.tensor([float(rank + 1)])
+    dist.all_reduce(t)
+    if os.environ.get("BENCH_SELFTEST_FAIL_RANK") == str(rank):
+        sys.exit(7)
+    dist.barrier()
+    if rank == 0:
+        print(json.dumps({"selftest": True, "n_gpus": world, "sum": float(t.item())}), flush=True)
+    dist.destroy_process_group()
+
+
+# =====================================================================================================
+# CPU baseline: the oracle in *faithful* mode on this box's host cores
+# =====================================================================================================
 def cpu_baseline(workload, budget_s=20.0):
-    """Time the oracle in *faithful* mode (the reference's algorithmic structure: full-length Jakes
-    synthesis, per-RE channel loop, SciPy griddata per antenna pair, dense PxP inverse) on the host
-    cores of this box.  One process per core, a bounded number of frames each."""
+    """Time the oracle in *faithful* mode (the reference's algorithmic structure: full-length Jakes synthesis, per-RE
+    channel loop, SciPy griddata per antenna pair, dense PxP inverse) on the host cores of this box.  One process per
+    core, a bounded number of frames each."""
     import multiprocessing as mp
-    T, R, N, cp, U, ct, fd, snr, dens, _ = WORKLOADS[workload]
+    w = WORKLOADS[workload]
     cores = min(os.cpu_count() or 1, 16)
-    # one frame costs ~0.5-1 s per core in faithful mode; scale the sample to ~budget_s of wall time
+    if w["kind"] == "fullcov":
+        cores = min(cores, 8)                                   # 16 dense 1678x1678 complex inverses per frame: bound the sample
     t0 = time.time()
-    _cpu_frames((workload, 1, 12345))                         # one frame to size the sample
+    _cpu_frames((workload, 1, 12345))                           # one frame to size the sample
     one = time.time() - t0
-    per_proc = max(1, int(budget_s / max(one, 1e-3)))
-    per_proc = min(per_proc, 32)
+    per_proc = max(1, min(32, int(budget_s / max(one, 1e-3))))
     ctx = mp.get_context("spawn")
     t0 = time.time()
     with ctx.Pool(cores) as pool:
@@ -69,6 +145,33 @@ def cpu_baseline(workload, budget_s=20.0):
                       f"(float64 NumPy/SciPy restatement with the reference's cost structure), {dt:.1f} s wall"}
 
 
+def fullcov_covariance(N, cp, U, T, ct, fd, pil, S=14):
+    """Harness-defined channel covariance at the pilots for config 5 (the reference has no covariance
+    generator): R[(s,k),(s',k')] = T * sum_l p_l exp(-2 pi j (kappa_k - kappa_k') d_l / N) * J0(2 pi f_d (t_s - t_s'));
+    the factor T reflects that the estimators observe sum_t H_{r,t} (quirk Q5/Q9)."""
+    from scipy.special import j0
+    fs = N * 15000.0
+    half = U // 2
+    nsc = 2 * half - 1
+    k = np.arange(nsc)
+    kap = np.where(k < half, k - half, k - half + 1)
+    # tap table after the reference's rounding (src/channel_simulator.py:75-81); duplicates overwrite (quirk Q1)
+    prof = {"EPA": ([0, 30, 70, 90, 110, 190, 410], [0.0, -1.0, -2.0, -3.0, -8.0, -17.2, -20.8]),
+            "EVA": ([0, 30, 150, 310, 370, 710, 1090, 1730, 2510], [0.0, -1.5, -1.4, -3.6, -0.6, -9.1, -7.0, -12.0, -16.9]),
+            "ETU": ([0, 50, 120, 200, 230, 500, 1600, 2300, 5000], [-1.0, -1.0, -1.0, 0.0, 0.0, 0.0, -3.0, -5.0, -7.0])}[ct]
+    p = 10.0 ** (np.asarray(prof[1]) / 10.0)
+    p = p / p.sum()
+    d = np.round(np.asarray(prof[0], dtype=np.float64) * 1e-9 * fs).astype(int)
+    taps = {}
+    for pl, dl in zip(p, d):
+        taps[int(dl)] = pl                                      # later path with the same delay wins
+    ps, pk = np.unravel_index(np.asarray(pil), (S, nsc))
+    dk = kap[pk][:, None] - kap[pk][None, :]
+    Rf = sum(pl * np.exp(-2j * np.pi * dk * dl / N) for dl, pl in taps.items())
+    ts = ps * (N + cp) / fs
+    return T * Rf * j0(2 * np.pi * fd * (ts[:, None] - ts[None, :]))
+
+
 def _cpu_frames(args):
     workload, n, seed = args
     os.environ.setdefault("OMP_NUM_THREADS", "1")
@@ -78,13 +181,19 @@ def _cpu_frames(args):
     except Exception:
         limiter = None
     from oracle import cpu_ref as O
-    T, R, N, cp, U, ct, fd, snr, dens, _ = WORKLOADS[workload]
+    w = WORKLOADS[workload]
+    T, R, N, cp, U = w["T"], w["R"], w["N"], w["cp"], w["U"]
     S = 14
     nsc = len(O.used_indices(N, U))
-    L = len(O.PROFILES[ct][0])
     rs = np.random.RandomState(seed)
     acc_ls = acc_mm = 0.0
     for _ in range(n):
+        if w["kind"] == "dataset":                              # the four np.random.choice of src/dataset_generator.py:114-117
+            ct = w["types"][rs.randint(len(w["types"]))]; fd = w["dopplers"][rs.randint(len(w["dopplers"]))]
+            snr = w["snrs"][rs.randint(len(w["snrs"]))]; dens = w["densities"][rs.randint(len(w["densities"]))]
+        else:
+            ct, fd, snr, dens = w["ct"], w["fd"], w["snr"], w["dens"]
+        L = len(O.PROFILES[ct][0])
         d = O.legacy_frame_draws(rs, S, nsc, T, R, L, dens)
         pos, mask = O.pattern_from_indices(d["pilot_indices"], S, nsc)
         pil = O.unit_symbols(d["u_pilot"])
@@ -93,40 +202,46 @@ def _cpu_frames(args):
         H = O.channel_frequency_response_faithful(ct, fd, N, cp, S, U, 15000.0, d["u_angle"], d["u_phase"])
         rx = O.apply_channel_faithful(tx, H, snr, d["n_re"], d["n_im"])
         rx4 = O.repeat_over_tx(rx, T)
-        ls = O.ls_estimate(rx4, pil, mask, pos, "linear")
-        mm = O.mmse_estimate(rx4, pil, mask, pos, snr, dense=True)
+        if w["kind"] == "fullcov":                              # MMSEEstimator(channel_covariance=R, estimate_statistics=False)
+            cov = fullcov_covariance(N, cp, U, T, ct, fd, d["pilot_indices"], S)
+            mm = O.mmse_estimate(rx4, pil, mask, pos, snr, covariance=cov, estimate_statistics=False)
+            ls = mm
+        else:
+            ls = O.ls_estimate(rx4, pil, mask, pos, "linear")
+            mm = O.mmse_estimate(rx4, pil, mask, pos, snr, dense=True)
         acc_ls += O.evaluate_estimator(H, ls)["mse"]
         acc_mm += O.evaluate_estimator(H, mm)["mse"]
     del limiter
     return n, acc_ls / n, acc_mm / n
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="cfg2_2x2_eva_ls_mmse", choices=sorted(WORKLOADS))
-    ap.add_argument("--frames", type=int, default=None, help="frames per step per GPU (default: the config's)")
-    ap.add_argument("--pattern-group", type=int, default=PATTERN_GROUP,
-                    help="frames sharing one pilot pattern + interpolation plan; 1 = a new random pattern per frame as the "
-                         "reference draws them (Qhull triangulation on the host, plan on the device, BEFORE the timed region)")
-    ap.add_argument("--plan-workers", type=int, default=0, help="host processes for plan building (0 = min(16, cores))")
-    ap.add_argument("--placement-tries", type=int, default=4,
-                    help="candidate allocations per output tensor group; the fastest placement is kept (1 = take the first)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--with-metrics", action="store_true", help="also produce the fused error sums inside the timed step")
-    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
-                    help="nccl (= RCCL, one GPU per rank) for real runs; gloo only to rehearse the N>1 control flow with "
-                         "several ranks sharing one GPU")
-    args = ap.parse_args()
+# =====================================================================================================
+# the measured job
+# =====================================================================================================
+def _pmc_traffic(workload, F, group):
+    """HBM bytes per frame-kernel launch from the committed PMC passes (profiles/pmc_traffic.json), only when the
+    record was collected on the CURRENT kernel source (sha of csrc/frame_kernel.hip) and this workload; else None."""
+    import hashlib
+    tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        rec = json.load(open(tfile))
+        sha = hashlib.sha256(open(os.path.join(ROOT, PKG, "csrc", "frame_kernel.hip"), "rb").read()).hexdigest()[:16]
+        if rec.get("workload") == workload and rec.get("frames") == F and group == PATTERN_GROUP and rec.get("kernel_source_sha16") == sha:
+            return rec.get("hbm_bytes_per_launch"), f"profiles/pmc_traffic.json @ {rec.get('commit', '?')}"
+    except Exception:
+        pass
+    return None, None
 
+
+def run(args):
     import torch
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world and world > 1:
+    if args.selftest_spawn:
+        return _selftest_spawn(world, rank)
+    if args.gpus != world:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if args.dist_backend == "gloo":
         local = local % max(1, torch.cuda.device_count())
@@ -140,52 +255,126 @@ def main():
     coll_dev = torch.device("cuda", local) if args.dist_backend == "nccl" else torch.device("cpu")
 
     E = importlib.import_module(PKG + ".engine")
-    T, R, N, cp, U, ct, fd, snr, dens, F = WORKLOADS[args.workload]
-    if args.frames:
-        F = args.frames
+    SH = importlib.import_module(PKG + ".sharding")
+    IP = importlib.import_module(PKG + ".interp_plan")
+    w = WORKLOADS[args.workload]
+    kind = w["kind"]
+    T, R, N, cp, U = w["T"], w["R"], w["N"], w["cp"], w["U"]
+    F = args.frames or w["frames"]
     geom = E.Geometry(fft_size=N, cp_length=cp, num_symbols=14, useful_subcarriers=U, num_tx=T, num_rx=R)
     eng = E.Engine(geom, local)
     S, nsc, G = geom.num_symbols, geom.num_sc, geom.grid
-    P = int(G * dens)
-
-    # ---- inputs resident in HBM before the timed region: patterns, plans, descriptors -------------
+    seed = 42 if kind == "dataset" else 2024
+    total_steps = args.warmup + args.steps
     group = max(1, args.pattern_group)
-    npat = (F + group - 1) // group
-    pils = []
-    for gidx in range(npat):
-        rs = np.random.RandomState(2024 + gidx)                # legacy shuffle, as PilotPattern does
-        perm = np.arange(G)
-        rs.shuffle(perm)
-        pils.append(np.sort(perm[:P]))
-    t_plan = time.perf_counter()
     workers = args.plan_workers or min(16, os.cpu_count() or 1)
-    eng.max_cached_patterns = max(eng.max_cached_patterns, npat + 8)
-    if npat >= 4 * workers:                 # Qhull Delaunay on the host (~2 ms per pattern per core); point location on the GPU.
-        IP = importlib.import_module(PKG + ".interp_plan")           # Uploads overlap the pool's remaining triangulations.
-        slots = [eng.pattern_slot(pil, "linear", plan=tri) for pil, tri in zip(pils, IP.triangulations_iter(pils, S, nsc, workers))]
+
+    # ---- inputs resident in HBM before the timed region: patterns, plans (descriptors too, except for the dataset) -------
+    t_plan = time.perf_counter()
+    if kind == "dataset":
+        # one pattern per (density, group of `group` consecutive GLOBAL frames) over the frame range this job will touch
+        dens_list = list(w["densities"])
+        first_group, last_group = 0, (total_steps * world * F - 1) // group
+        pils, keys = [], []
+        for di, d in enumerate(dens_list):
+            for gidx in range(first_group, last_group + 1):
+                perm = np.arange(G)
+                np.random.RandomState((seed * 1000003 + gidx * 101 + di) % (2 ** 32)).shuffle(perm)   # PilotPattern's shuffle
+                pils.append(np.sort(perm[: int(G * d)])); keys.append((di, gidx))
+    elif kind == "fullcov":
+        perm = np.arange(G)
+        np.random.RandomState(2024).shuffle(perm)
+        pils = [np.sort(perm[: int(G * w["dens"])])]
+    else:
+        npat = (F + group - 1) // group
+        pils = []
+        for gidx in range(npat):
+            perm = np.arange(G)
+            np.random.RandomState(2024 + gidx).shuffle(perm)
+            pils.append(np.sort(perm[: int(G * w["dens"])]))
+    eng.max_cached_patterns = max(eng.max_cached_patterns, len(pils) + 8)
+    if len(pils) >= 4 * workers:            # Qhull Delaunay on the host (~2 ms per pattern per core); point location on the GPU;
+        slots = [eng.pattern_slot(pil, "linear", plan=tri)            # uploads overlap the pool's remaining triangulations
+                 for pil, tri in zip(pils, IP.triangulations_iter(pils, S, nsc, workers))]
     else:
         workers = 1
         slots = [eng.pattern_slot(pil, "linear") for pil in pils]
     t_plan = time.perf_counter() - t_plan
-    slot_of_frame = np.asarray(slots, dtype=np.int32)[np.arange(F) // group]
-    descs = E.make_descs(ct, fd, snr, slot_of_frame, n=F)
-    d_dev = torch.from_numpy(descs.view(np.uint8).copy()).to(eng.device)
+    P = max(len(p) for p in pils)
+
     names = ["tx", "rx", "H", "H_ls", "H_mmse", "pilot_symbols", "pilot_mask"]
-    if args.with_metrics:
-        names.append("metrics")
-    # Output buffers are allocated once and reused by every step.  Where they live matters on MI355X (Engine.place_outputs,
-    # DESIGN.md section 5): probe a few placements per tensor group with the real kernel and keep the fastest.
-    out, placement = eng.place_outputs(d_dev, names, seed=2024, tries=args.placement_tries)
+    extra = {}
+    if kind == "dataset":
+        names = ["tx", "rx", "H", "H_ls", "H_mmse", "pilot_mask_f32", "metrics"]       # the stacked record of run_phase3_dataset_generation.py:135-143 (+H_mmse)
+        slot_of = np.full((len(dens_list), last_group + 1), -1, dtype=np.int32)
+        for (di, gidx), sl in zip(keys, slots):
+            slot_of[di, gidx] = sl
+        types_code = np.asarray([E.channel_code(c) for c in w["types"]], dtype=np.int32)
+        dop = np.asarray(w["dopplers"], np.float32); snrs = np.asarray(w["snrs"], np.float32)
+
+        def descs_for(b0):
+            idx = np.arange(b0, b0 + F, dtype=np.int64)
+            ci, di, si, pi = SH.frame_choices(seed, idx, (len(types_code), len(dop), len(snrs), len(dens_list)))
+            d = np.empty(F, dtype=E.DESC_DTYPE)
+            d["channel_type"] = types_code[ci]; d["doppler_hz"] = dop[di]; d["snr_db"] = snrs[si]
+            d["pattern_slot"] = slot_of[pi, idx // group]
+            return d
+        d_first = descs_for(rank * F)
+    else:
+        if kind == "fullcov":
+            names = ["tx", "rx", "H", "pilot_symbols", "pilot_mask", "h_ls_pilots"]
+            slot_of_frame = np.full(F, slots[0], dtype=np.int32)
+        else:
+            slot_of_frame = np.asarray(slots, dtype=np.int32)[np.arange(F) // group]
+            if args.with_metrics:
+                names.append("metrics")
+        descs = E.make_descs(w["ct"], w["fd"], w["snr"], slot_of_frame, n=F)
+        d_first = torch.from_numpy(descs.view(np.uint8).copy()).to(eng.device)
+
+    # Output buffers are allocated once and reused by every step (--placement-tries > 1 probes several allocations with
+    # the real kernel and keeps the fastest, Engine.place_outputs; the default takes the first allocation).
+    out, placement = eng.place_outputs(d_first, names, seed=seed, tries=args.placement_tries)
     torch.cuda.synchronize()
+
+    if kind == "fullcov":
+        # W = R (R + sigma^2 I)^-1 once, on rank 0, float64 on the device; broadcast over RCCL before the timed region
+        Pn = len(pils[0])
+        W = eng.empty_c64(Pn, Pn)
+        t_prep = time.perf_counter()
+        if rank == 0:
+            cov = fullcov_covariance(N, cp, U, T, w["ct"], w["fd"], pils[0], S)
+            W.copy_(eng.mmse_full_prepare(cov, w["snr"]))
+            torch.cuda.synchronize()
+        t_prep = time.perf_counter() - t_prep
+        if world > 1:
+            if args.dist_backend == "nccl":
+                SH.broadcast_from_root(W, 0)
+            else:
+                Wc = W.cpu(); SH.broadcast_from_root(Wc, 0); W.copy_(Wc)
+        scr = eng.mmse_full_scratch(slots[0], F * R)
+        out["H_mmse"] = eng.empty_c64(F, S, R, T, nsc)
+        extra.update(prepare_s=round(t_prep, 3))
 
     def step(i):
         off = (i * world + rank) * F
-        eng.run_frames(d_dev, seed=2024, frame_offset=off, outputs=names, out=out, check=False)
+        if kind == "dataset":
+            eng.run_frames(descs_for(off), seed=seed, frame_offset=off, outputs=names, out=out, check=False)
+        elif kind == "fullcov":
+            eng.run_frames(d_first, seed=seed, frame_offset=off, outputs=names, out=out, check=False)
+            eng.mmse_full_apply_pilots(out["h_ls_pilots"], slots[0], W, out=out["H_mmse"], scratch=scr)
+        else:
+            eng.run_frames(d_first, seed=seed, frame_offset=off, outputs=names, out=out, check=False)
 
     # est-MSE is evaluate_estimator's job, not part of the LS+MMSE step: one extra UNTIMED launch with the fused
-    # error-sum output gives the numbers reported under "est_mse".
-    mse_out = eng.run_frames(d_dev, seed=2024, frame_offset=rank * F, outputs=("metrics",))["metrics"].double()
-    summ = torch.stack([mse_out[:, 0].sum(), mse_out[:, 1].sum(), mse_out[:, 2].sum(), mse_out[:, 6].sum()])   # this rank's partial sums
+    # error-sum output gives the numbers reported under "est_mse" (fullcov: error sums of the stored tensors).
+    if kind == "fullcov":
+        step(0)
+        es = eng.error_sums(out["H"], out["H_mmse"]).double()
+        cnt = float(out["H"].numel())
+        summ = torch.stack([es[1], es[0], es[0], torch.tensor(cnt, dtype=torch.float64, device=es.device)])
+    else:
+        mse_out = eng.run_frames(d_first, seed=seed, frame_offset=rank * F, outputs=("metrics",))["metrics"].double()
+        summ = torch.stack([mse_out[:, 0].sum(), mse_out[:, 1].sum(), mse_out[:, 2].sum(), mse_out[:, 6].sum()])
     for i in range(args.warmup):
         step(i)
     if world > 1:
@@ -198,12 +387,13 @@ def main():
         ev[i][0].record()
         step(args.warmup + i)
         ev[i][1].record()
-    # the job's single collective: per-rank metric sums to every rank (RCCL over xGMI)
+    # the job's single collective: per-rank metric sums gathered to rank 0 (RCCL over xGMI)
     if world > 1:
         summ_c = summ.to(coll_dev)
-        gathered = [torch.zeros_like(summ_c) for _ in range(world)]
-        dist.all_gather(gathered, summ_c)
-        summ = torch.stack(gathered).sum(0)
+        gathered = [torch.zeros_like(summ_c) for _ in range(world)] if rank == 0 else None
+        dist.gather(summ_c, gathered, dst=0)
+        if rank == 0:
+            summ = torch.stack(gathered).sum(0)
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
@@ -212,49 +402,97 @@ def main():
         tmax = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
-    call_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))      # one chest_frames_run call = taps + frame kernels
-    taps_ms, kern_ms, _ = eng.profile_read()                             # each kernel on its own
+    call_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))      # one step on the stream (all its kernels)
+    kern = eng.profile_read_all()                                        # {kernel name: average ms per launch}
     eng.profile_begin(0)
 
     if rank == 0:
-        bytes_frame = algorithmic_bytes_per_frame(S, nsc, T, R, P, 2)
-        if group == 1:          # a plan of its own per frame has to be read: 16-B record per RE + 4-B pilot index
+        taps_ms, kern_ms = kern.get("taps_kernel", 0.0), kern.get("frame_kernel", 0.0)
+        cfgd = {"workload": args.workload, "frames_per_step_per_gpu": F, "mimo": f"{T}x{R}", "fft_size": N, "pilots": P,
+                "pattern_group": group, "patterns": len(pils), "host_plan_build_s": round(t_plan, 2),
+                "host_plan_workers": workers, "output_placement": placement, "rng": "Philox4x32-10 on device",
+                "outputs": names, "parallelism": f"frames sharded x{world}", "dist_backend": args.dist_backend if world > 1 else None}
+        if kind == "dataset":
+            Pavg = float(np.mean([int(G * d) for d in w["densities"]]))
+            bytes_frame = algorithmic_bytes_per_frame(S, nsc, T, R, 0, 2, mask_bytes=4, extra=4 * 8)
+            cfgd.update(channel=list(w["types"]), doppler_hz=list(w["dopplers"]), snr_db=list(w["snrs"]),
+                        pilot_density=list(w["densities"]), pilots_mean=Pavg,
+                        path="dataset_generator loop body: 4 choices + simulate_transmission + LSEstimator.estimate + MMSEEstimator.estimate per frame",
+                        estimators="LS(linear)+MMSE(diag)", host_descriptor_generation="inside the timed step")
+        elif kind == "fullcov":
+            bytes_frame = algorithmic_bytes_per_frame(S, nsc, T, R, P, 1)
+            cfgd.update(channel=w["ct"], doppler_hz=w["fd"], snr_db=w["snr"], pilot_density=w["dens"],
+                        path="simulate_transmission + MMSEEstimator(channel_covariance, estimate_statistics=False).estimate per frame",
+                        estimators="MMSE(full covariance, W prepared once in float64 on the device)", **extra)
+        else:
+            bytes_frame = algorithmic_bytes_per_frame(S, nsc, T, R, P, 2)
+            cfgd.update(channel=w["ct"], doppler_hz=w["fd"], snr_db=w["snr"], pilot_density=w["dens"],
+                        path="simulate_transmission + LSEstimator.estimate + MMSEEstimator.estimate per frame",
+                        estimators="LS(linear)+MMSE(diag)")
+        if group == 1 and kind != "fullcov":   # a plan of its own per frame has to be read: 16-B record per RE + 4-B pilot index
             bytes_frame += 16 * G + 4 * P
-        achieved = bytes_frame * F / (kern_ms * 1e-3) / 1e9
-        traffic = None
-        tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tfile):
-            try:
-                rec = json.load(open(tfile))
-                if rec.get("workload") == args.workload and rec.get("frames") == F and group == PATTERN_GROUP:
-                    traffic = rec.get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        if kind == "fullcov":
+            gemm_ms = kern.get("cgemm_w_kernel_3m", 0.0)
+            flop = 8.0 * P * P * R * F                               # one right-hand side per (frame, rx): quirk Q9
+            ach = flop / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+            step_ms = dt / args.steps * 1e3
+            hbm = bytes_frame * F / (step_ms * 1e-3) / 1e9
+            roof = {"bound": "mfma", "achieved": ach, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": ach / MFMA_F32_PEAK_TFLOPS, "traffic": None, "kernel": "cgemm_w_kernel_3m", "kernel_ms": gemm_ms,
+                    "flop_per_frame": 8.0 * P * P * R, "kernels_ms": kern, "call_ms": call_ms,
+                    "hbm_whole_step": {"bytes_per_frame": bytes_frame, "achieved_GBps": hbm, "frac": hbm / HBM_PEAK_GBS}}
+        else:
+            achieved = bytes_frame * F / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
+            traffic, tsrc = _pmc_traffic(args.workload, F, group)
+            roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": tsrc, "kernel": "frame_kernel",
+                    "kernel_ms": kern_ms, "taps_kernel_ms": taps_ms, "call_ms": call_ms, "bytes_per_frame": bytes_frame}
         s = summ.cpu().numpy()
         res = {
             "metric": "OFDM frames/sec (LS+MMSE)", "value": F * world * args.steps / dt, "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": args.workload, "frames_per_step_per_gpu": F, "mimo": f"{T}x{R}", "fft_size": N,
-                       "channel": ct, "doppler_hz": fd, "snr_db": snr, "pilot_density": dens, "pilots": P,
-                       "path": "simulate_transmission + LSEstimator.estimate + MMSEEstimator.estimate per frame",
-                       "estimators": "LS(linear)+MMSE(diag)", "pattern_group": group, "patterns": npat,
-                       "host_plan_build_s": round(t_plan, 2), "host_plan_workers": workers,
-                       "output_placement": placement,
-                       "rng": "Philox4x32-10 on device", "outputs": names, "parallelism": f"frames sharded x{world}"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "frame_kernel",
-                         "kernel_ms": kern_ms, "taps_kernel_ms": taps_ms, "call_ms": call_ms,
-                         "bytes_per_frame": bytes_frame},
+            "config": cfgd, "roofline": roof,
         }
         if s[3] > 0:
             res["est_mse"] = {"ls": float(s[1] / s[3]), "mmse": float(s[2] / s[3]),
                               "nmse_db_ls": float(10 * np.log10(s[1] / s[0])), "nmse_db_mmse": float(10 * np.log10(s[2] / s[0]))}
+            if kind == "fullcov":
+                res["est_mse"].pop("ls"); res["est_mse"].pop("nmse_db_ls")
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(args.workload)
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="cfg2_2x2_eva_ls_mmse", choices=sorted(WORKLOADS))
+    ap.add_argument("--frames", type=int, default=None, help="frames per step per GPU (default: the config's)")
+    ap.add_argument("--pattern-group", type=int, default=PATTERN_GROUP,
+                    help="frames sharing one pilot pattern + interpolation plan; 1 = a new random pattern per frame as the "
+                         "reference draws them (plans built BEFORE the timed region)")
+    ap.add_argument("--plan-workers", type=int, default=0, help="host processes for plan building (0 = min(16, cores))")
+    ap.add_argument("--placement-tries", type=int, default=1,
+                    help="candidate allocations per output tensor group (1 = take the first allocation, the default; "
+                         ">1 probes placements with the real kernel and keeps the fastest)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--with-metrics", action="store_true", help="also produce the fused error sums inside the timed step")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl (= RCCL, one GPU per rank) for real runs; gloo only to rehearse the N>1 control flow with "
+                         "several ranks sharing one GPU")
+    ap.add_argument("--selftest-spawn", action="store_true", help=argparse.SUPPRESS)
+    args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher: start the ranks ourselves, before anything here touches the GPU (torch is not even imported yet)
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
+    run(args)
 
 
 if __name__ == "__main__":

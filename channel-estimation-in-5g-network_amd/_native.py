@@ -14,6 +14,10 @@ MAX_PATHS = 16
 NUM_OSC = 20
 NUM_METRICS = 8
 M_SUM_H2, M_SUM_ERR_LS, M_SUM_ERR_MMSE, M_SIGNAL_POWER, M_NOISE_STD, M_ALPHA0, M_COUNT = range(7)
+ABI_VERSION = 2
+FRAME_OK, FRAME_BAD_DESC, FRAME_NO_PLAN = 0, 1, 2
+KERNEL_IDS = {"taps_kernel": 0, "frame_kernel": 1, "pack_kernels": 2, "cgemm_w_kernel_3m": 3, "interp_from_pilots_kernel": 4,
+              "plan_kernels": 5}
 CHANNEL_CODES = {"EPA": 0, "EVA": 1, "ETU": 2}
 
 
@@ -41,7 +45,7 @@ class FrameOutputs(C.Structure):
     _fields_ = [("tx", C.c_void_p), ("rx", C.c_void_p), ("H", C.c_void_p), ("H_ls", C.c_void_p),
                 ("H_mmse", C.c_void_p), ("pilot_symbols", C.c_void_p), ("pilot_mask", C.c_void_p),
                 ("metrics", C.c_void_p), ("pilot_stride", C.c_int32), ("h_ls_stride", C.c_int32),
-                ("h_ls_pilots", C.c_void_p)]
+                ("h_ls_pilots", C.c_void_p), ("pilot_mask_f32", C.c_void_p), ("frame_status", C.c_void_p)]
 
 
 # name -> (restype, argtypes); this table is also what tests/test_abi_symbols.py checks against chest.h
@@ -60,6 +64,8 @@ SIGNATURES = {
     "chest_get_status": (_i32, [_vp, C.POINTER(_i32)]),
     "chest_profile_begin": (_i32, [_vp, _i32]),
     "chest_profile_read": (_i32, [_vp, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(_i32)]),
+    "chest_profile_read_kernel": (_i32, [_vp, _i32, C.POINTER(C.c_float), C.POINTER(_i32)]),
+    "chest_tune": (_i32, [_vp, C.c_char_p, _i32]),
     "chest_frames_workspace_bytes": (_i64, [_vp, _i32]),
     "chest_frames_run": (_i32, [_vp, _vp, _i32, _vp, _u64, _u64, C.POINTER(Injected), C.POINTER(FrameOutputs), _vp, _i64]),
     "chest_estimate_batch": (_i32, [_vp, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _f, _vp]),

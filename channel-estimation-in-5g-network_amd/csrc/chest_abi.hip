@@ -86,10 +86,6 @@ static int build_tables(chest_ctx* ctx) {
     // frame kernel: wave <-> OFDM symbol; two symbols per wave measured best on MI355X (7 waves for S = 14)
     const int nwaves = (fp.S + 1) / 2;
     ctx->block_threads = (nwaves > 16 ? 16 : nwaves) * 64;
-    if (const char* e = getenv("CHEST_BLOCK_THREADS")) {          // tuning knob for experiments
-        const int v = atoi(e);
-        if (v >= 64 && v <= 1024 && v % 64 == 0) ctx->block_threads = v;
-    }
     return CHEST_OK;
 }
 
@@ -139,7 +135,8 @@ int chest_create(const chest_config* cfg, chest_ctx** out) {
     int ndev = 0;
     CHEST_HIP(hipGetDeviceCount(&ndev));
     if (cfg->device < 0 || cfg->device >= ndev) { set_error("chest_create: device %d of %d", cfg->device, ndev); return CHEST_EINVAL; }
-    CHEST_HIP(hipSetDevice(cfg->device));
+    chest::DeviceGuard guard_(cfg->device);                      // the caller's current device is restored on return
+    if (!guard_.ok) { set_error("hipSetDevice(%d) failed", cfg->device); return CHEST_EHIP; }
     chest_ctx* ctx = new (std::nothrow) chest_ctx();
     if (!ctx) { set_error("out of host memory"); return CHEST_ENOMEM; }
     ctx->cfg = *cfg;
@@ -183,7 +180,7 @@ int chest_create(const chest_config* cfg, chest_ctx** out) {
 
 void chest_destroy(chest_ctx* ctx) {
     if (!ctx) return;
-    (void)hipSetDevice(ctx->cfg.device);
+    chest::DeviceGuard guard_(ctx->cfg.device);
     (void)hipDeviceSynchronize();
     for (auto& p : ctx->patterns)
         if (p.block) (void)hipFree(p.block);
@@ -192,7 +189,7 @@ void chest_destroy(chest_ctx* ctx) {
     if (ctx->d_twiddle) (void)hipFree(ctx->d_twiddle);
     if (ctx->d_gram) (void)hipFree(ctx->d_gram);
     if (ctx->d_fp) (void)hipFree(ctx->d_fp);
-    for (void* e : ctx->prof_events) (void)hipEventDestroy((hipEvent_t)e);
+    for (auto& sp : ctx->prof_spans) { (void)hipEventDestroy((hipEvent_t)sp.a); (void)hipEventDestroy((hipEvent_t)sp.b); }
     delete ctx;
 }
 
@@ -239,7 +236,7 @@ static int pattern_set_impl(chest_ctx* ctx, int32_t slot, const int32_t* pilot_i
                 return CHEST_EINVAL;
             }
     const bool with_plan = plan_idx != nullptr || simplices != nullptr;
-    CHEST_HIP(hipSetDevice(ctx->cfg.device));
+    CHEST_GUARD(ctx);
     // draw slot of every resource element: i-th pilot <-> i-th True of the row-major mask
     // (insert_pilots, src/channel_simulator.py:249-252); data symbols follow in row-major order.
     std::vector<uint16_t> slots(G);
@@ -329,7 +326,7 @@ int chest_pattern_get_plan(chest_ctx* ctx, int32_t slot, uint16_t* plan_idx, flo
     const int G = ctx->fp.G;
     struct Rec { float w0, w1; uint32_t i01, i2v; };
     std::vector<Rec> recs(G);
-    CHEST_HIP(hipSetDevice(ctx->cfg.device));
+    CHEST_GUARD(ctx);
     CHEST_HIP(hipMemcpy(recs.data(), ctx->patterns[slot].dev.plan, (size_t)G * sizeof(Rec), hipMemcpyDeviceToHost));
     for (int g = 0; g < G; ++g) {
         const Rec& r = recs[g];
@@ -352,7 +349,7 @@ int chest_pattern_num_pilots(chest_ctx* ctx, int32_t slot) {
 
 int chest_get_status(chest_ctx* ctx, int32_t* status) {
     if (!ctx || !status) { set_error("null argument"); return CHEST_EINVAL; }
-    CHEST_HIP(hipSetDevice(ctx->cfg.device));
+    CHEST_GUARD(ctx);
     CHEST_HIP(hipMemcpy(status, ctx->d_status, sizeof(int32_t), hipMemcpyDeviceToHost));
     if (*status != 0) CHEST_HIP(hipMemset(ctx->d_status, 0, sizeof(int32_t)));
     return CHEST_OK;
@@ -365,34 +362,52 @@ int64_t chest_frames_workspace_bytes(chest_ctx* ctx, int32_t num_frames) {
 
 int chest_profile_begin(chest_ctx* ctx, int32_t capacity) {
     if (!ctx || capacity < 0) { set_error("chest_profile_begin: bad argument"); return CHEST_EINVAL; }
-    CHEST_HIP(hipSetDevice(ctx->cfg.device));
-    for (void* e : ctx->prof_events) (void)hipEventDestroy((hipEvent_t)e);
-    ctx->prof_events.clear();
+    CHEST_GUARD(ctx);
+    for (auto& sp : ctx->prof_spans) { (void)hipEventDestroy((hipEvent_t)sp.a); (void)hipEventDestroy((hipEvent_t)sp.b); }
+    ctx->prof_spans.clear();
     ctx->prof_used = 0;
-    for (int i = 0; i < capacity * 3; ++i) {
-        hipEvent_t ev = nullptr;
-        CHEST_HIP(hipEventCreate(&ev));
-        ctx->prof_events.push_back(ev);
+    for (int i = 0; i < capacity * 8; ++i) {
+        hipEvent_t a = nullptr, b = nullptr;
+        CHEST_HIP(hipEventCreate(&a));
+        CHEST_HIP(hipEventCreate(&b));
+        ctx->prof_spans.push_back({0, a, b});
     }
+    return CHEST_OK;
+}
+
+int chest_profile_read_kernel(chest_ctx* ctx, int32_t kernel_id, float* ms, int32_t* count) {
+    if (!ctx || !ms || !count) { set_error("chest_profile_read_kernel: null argument"); return CHEST_EINVAL; }
+    CHEST_GUARD(ctx);
+    double t = 0.0;
+    int n = 0;
+    for (int i = 0; i < ctx->prof_used; ++i) {
+        const auto& sp = ctx->prof_spans[i];
+        if (sp.id != kernel_id) continue;
+        CHEST_HIP(hipEventSynchronize((hipEvent_t)sp.b));
+        float a = 0.f;
+        CHEST_HIP(hipEventElapsedTime(&a, (hipEvent_t)sp.a, (hipEvent_t)sp.b));
+        t += a; ++n;
+    }
+    *count = n;
+    *ms = n ? (float)(t / n) : 0.f;
     return CHEST_OK;
 }
 
 int chest_profile_read(chest_ctx* ctx, float* taps_ms, float* frame_ms, int32_t* count) {
     if (!ctx || !taps_ms || !frame_ms || !count) { set_error("chest_profile_read: null argument"); return CHEST_EINVAL; }
-    double t = 0.0, f = 0.0;
-    for (int i = 0; i < ctx->prof_used; ++i) {
-        hipEvent_t* e = (hipEvent_t*)&ctx->prof_events[(size_t)i * 3];
-        CHEST_HIP(hipEventSynchronize(e[2]));
-        float a = 0.f, b = 0.f;
-        CHEST_HIP(hipEventElapsedTime(&a, e[0], e[1]));
-        CHEST_HIP(hipEventElapsedTime(&b, e[1], e[2]));
-        t += a; f += b;
-    }
-    *count = ctx->prof_used;
-    *taps_ms = ctx->prof_used ? (float)(t / ctx->prof_used) : 0.f;
-    *frame_ms = ctx->prof_used ? (float)(f / ctx->prof_used) : 0.f;
+    int32_t n1 = 0;
+    int rc = chest_profile_read_kernel(ctx, CHEST_K_TAPS, taps_ms, &n1);
+    if (rc == CHEST_OK) rc = chest_profile_read_kernel(ctx, CHEST_K_FRAME, frame_ms, count);
     ctx->prof_used = 0;
-    return CHEST_OK;
+    return rc;
+}
+
+int chest_tune(chest_ctx* ctx, const char* key, int32_t value) {
+    if (!ctx || !key) { set_error("chest_tune: null argument"); return CHEST_EINVAL; }
+    if (strcmp(key, "frame_rx_group") == 0) { ctx->tune_rx_group = value; return CHEST_OK; }
+    if (strcmp(key, "frame_legacy_rows") == 0) { ctx->tune_legacy_rows = value != 0; return CHEST_OK; }
+    set_error("chest_tune: unknown key '%s'", key);
+    return CHEST_EINVAL;
 }
 
 int chest_frames_run(chest_ctx* ctx, void* stream, int32_t B, const chest_frame_desc* descs, uint64_t seed,
@@ -411,6 +426,7 @@ int chest_frames_run(chest_ctx* ctx, void* stream, int32_t B, const chest_frame_
         for (const auto& p : ctx->patterns) Pmax = p.dev.P > Pmax ? p.dev.P : Pmax;
         if (out->h_ls_stride < Pmax) { set_error("h_ls_stride %d < largest pattern %d", out->h_ls_stride, Pmax); return CHEST_EINVAL; }
     }
+    CHEST_GUARD(ctx);
     return launch_frames(ctx, (hipStream_t)stream, B, descs, seed, frame_offset, inj, out, workspace, workspace_bytes);
 }
 
@@ -418,50 +434,59 @@ int chest_estimate_batch(chest_ctx* ctx, void* stream, int32_t B, const float* r
                          int32_t pilot_stride, int32_t slot, int32_t mmse, float snr_db, float* H_est) {
     if (!ctx || (B > 0 && (!rx4d || !tx_pilots || !H_est))) { set_error("chest_estimate_batch: null argument"); return CHEST_EINVAL; }
     if (B < 0 || pilot_stride < 0) { set_error("chest_estimate_batch: negative size"); return CHEST_EINVAL; }
+    CHEST_GUARD(ctx);
     return launch_estimate(ctx, (hipStream_t)stream, B, rx4d, tx_pilots, pilot_stride, slot, mmse, snr_db, H_est);
 }
 
 int chest_at_pilots(chest_ctx* ctx, void* stream, int32_t n, const float* rx, const float* tx, int32_t mmse,
                     float snr_db, float* out) {
     if (!ctx || n < 0 || (n > 0 && (!rx || !tx || !out))) { set_error("chest_at_pilots: bad argument"); return CHEST_EINVAL; }
+    CHEST_GUARD(ctx);
     return launch_at_pilots(ctx, (hipStream_t)stream, n, rx, tx, mmse, snr_db, out);
 }
 
 int chest_error_sums(chest_ctx* ctx, void* stream, int64_t n, const float* a, const float* b, double* out) {
     if (!ctx || n < 0 || !out || (n > 0 && (!a || !b))) { set_error("chest_error_sums: bad argument"); return CHEST_EINVAL; }
+    CHEST_GUARD(ctx);
     return launch_error_sums(ctx, (hipStream_t)stream, n, a, b, out);
 }
 
 int chest_apply_channel(chest_ctx* ctx, void* stream, int32_t B, const float* tx, const float* H, const float* snr_db,
                         const float* n_re, const float* n_im, uint64_t seed, uint64_t frame_offset, float* rx) {
     if (!ctx || B < 0 || (B > 0 && (!tx || !H || !snr_db || !rx))) { set_error("chest_apply_channel: bad argument"); return CHEST_EINVAL; }
+    CHEST_GUARD(ctx);
     return launch_apply_channel(ctx, (hipStream_t)stream, B, tx, H, snr_db, n_re, n_im, seed, frame_offset, rx);
 }
 
 int chest_time_varying_channel(chest_ctx* ctx, void* stream, int32_t type, float fd, int64_t ns, int32_t T, int32_t R,
                                const float* ua, const float* up, uint64_t seed, uint64_t frame, float* out) {
     if (!ctx || ns < 0 || T < 0 || R < 0 || (ns > 0 && !out)) { set_error("chest_time_varying_channel: bad argument"); return CHEST_EINVAL; }
+    CHEST_GUARD(ctx);
     return launch_tv_channel(ctx, (hipStream_t)stream, type, fd, ns, T, R, ua, up, seed, frame, out);
 }
 
 int chest_ofdm_modulate(chest_ctx* ctx, void* stream, int32_t n, const float* sym, float* out) {
     if (!ctx || n < 0 || (n > 0 && (!sym || !out))) { set_error("chest_ofdm_modulate: bad argument"); return CHEST_EINVAL; }
+    CHEST_GUARD(ctx);
     return launch_ofdm(ctx, (hipStream_t)stream, n, sym, out, true);
 }
 
 int chest_ofdm_demodulate(chest_ctx* ctx, void* stream, int32_t n, const float* tin, float* out) {
     if (!ctx || n < 0 || (n > 0 && (!tin || !out))) { set_error("chest_ofdm_demodulate: bad argument"); return CHEST_EINVAL; }
+    CHEST_GUARD(ctx);
     return launch_ofdm(ctx, (hipStream_t)stream, n, tin, out, false);
 }
 
 int chest_equalize(chest_ctx* ctx, void* stream, int32_t B, const float* rx, const float* H, int32_t method, float* out) {
     if (!ctx || B < 0 || (B > 0 && (!rx || !H || !out))) { set_error("chest_equalize: bad argument"); return CHEST_EINVAL; }
+    CHEST_GUARD(ctx);
     return launch_equalize(ctx, (hipStream_t)stream, B, rx, H, method, out);
 }
 
 int chest_tdl_apply(chest_ctx* ctx, void* stream, int32_t type, int64_t ns, int32_t T, int32_t R, const float* x, const float* h,
                     float* y) {
     if (!ctx || ns < 0 || T < 0 || R < 0 || (ns > 0 && (!x || !h || !y))) { set_error("chest_tdl_apply: bad argument"); return CHEST_EINVAL; }
+    CHEST_GUARD(ctx);
     return launch_tdl(ctx, (hipStream_t)stream, type, ns, T, R, x, h, y);
 }
 
@@ -471,6 +496,7 @@ int chest_pack_ml_inputs(chest_ctx* ctx, void* stream, int32_t B, const float* r
         set_error("chest_pack_ml_inputs: bad argument");
         return CHEST_EINVAL;
     }
+    CHEST_GUARD(ctx);
     return launch_pack_ml(ctx, (hipStream_t)stream, B, rx, H_ls, H_true, mask, normalize, inputs, targets);
 }
 
@@ -481,6 +507,7 @@ int chest_qam_modulate(chest_ctx* ctx, void* stream, int32_t M, int64_t n, const
         set_error("chest_qam_modulate: bad argument (bits must be 4-byte aligned)");
         return CHEST_EINVAL;
     }
+    CHEST_GUARD(ctx);
     return launch_qam_mod(ctx, (hipStream_t)stream, M, n, bits, wide, symbols);
 }
 
@@ -489,11 +516,13 @@ int chest_qam_demodulate(chest_ctx* ctx, void* stream, int32_t M, int64_t n, int
         set_error("chest_qam_demodulate: bad argument (bits must be 4-byte aligned)");
         return CHEST_EINVAL;
     }
+    CHEST_GUARD(ctx);
     return launch_qam_demod(ctx, (hipStream_t)stream, M, n, wide, symbols, bits);
 }
 
 int chest_bit_errors(chest_ctx* ctx, void* stream, int64_t n, const uint8_t* a, const uint8_t* b, uint64_t* count) {
     if (!ctx || n < 0 || !count || (n > 0 && (!a || !b))) { set_error("chest_bit_errors: bad argument"); return CHEST_EINVAL; }
+    CHEST_GUARD(ctx);
     return launch_bit_errors(ctx, (hipStream_t)stream, n, a, b, count);
 }
 

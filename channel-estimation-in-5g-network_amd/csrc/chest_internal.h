@@ -67,9 +67,13 @@ struct chest_ctx {
     float2* d_twiddle = nullptr;   // FFT twiddles exp(-2 pi j n/N), n < N (power-of-two N only)
     float2* d_gram = nullptr;      // [3][KT][KT] Gram matrices of the tap twiddles over the used bins
     chest::FrameParams* d_fp = nullptr;   // device copy of fp (kernels read it through uniform scalar loads)
-    std::vector<void*> prof_events;       // hipEvent_t triples (before taps, before frame kernel, after) when profiling
-    int32_t prof_used = 0;                // triples recorded since chest_profile_begin
-    size_t lds_opt_in[6] = {0, 0, 0, 0, 0, 0};   // largest dynamic-LDS size already opted in per kernel (per context = per device)
+    struct ProfSpan { int32_t id; void* a; void* b; };     // hipEvent_t pair around one kernel (group) of kind `id` (CHEST_K_*)
+    std::vector<ProfSpan> prof_spans;     // pool created by chest_profile_begin; launches never allocate
+    int32_t prof_used = 0;                // spans recorded since chest_profile_begin / the last chest_profile_read
+    size_t lds_opt_in[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // largest dynamic-LDS size already opted in per kernel (per context = per device)
+    // chest_tune (tools / experiments only; nothing on the launch path reads the environment)
+    int32_t tune_rx_group = 0;            // rx antennas per slab unit of the frame kernel (0 = chosen from the LDS budget)
+    int32_t tune_legacy_rows = 0;         // 1 = previous row-store frame kernel (kept for in-process A/B)
 };
 
 namespace chest {
@@ -84,7 +88,35 @@ void set_error(const char* fmt, ...);
         }                                                                            \
     } while (0)
 
-enum { LDS_TAPS = 0, LDS_FRAME = 1, LDS_ESTIMATE = 2, LDS_INTERP = 3, LDS_GEMM = 4, LDS_GEMM3M = 5 };
+enum { LDS_TAPS = 0, LDS_FRAME = 1, LDS_ESTIMATE = 2, LDS_INTERP = 3, LDS_GEMM = 4, LDS_GEMM3M = 5, LDS_FRAME_640 = 6,
+       LDS_FRAME_1024 = 7, LDS_FRAME_ROWS = 8, LDS_DELAUNAY = 9 };
+
+// RAII: make the context's device current for the duration of an entry point and restore the caller's afterwards
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = false;
+    explicit DeviceGuard(int device) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        ok = (prev == device) || hipSetDevice(device) == hipSuccess;
+        if (prev == device) prev = -1;                            // nothing to restore
+    }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+#define CHEST_GUARD(ctx)                                                                     \
+    chest::DeviceGuard guard_((ctx)->cfg.device);                                             \
+    if (!guard_.ok) { chest::set_error("hipSetDevice(%d) failed", (ctx)->cfg.device); return CHEST_EHIP; }
+
+// per-kernel timing spans (chest_profile_begin): record an event pair on the launch stream around a kernel group
+inline int prof_open(chest_ctx* ctx, hipStream_t st, int id) {
+    if ((size_t)ctx->prof_used >= ctx->prof_spans.size()) return -1;
+    const int i = ctx->prof_used++;
+    ctx->prof_spans[i].id = id;
+    (void)hipEventRecord((hipEvent_t)ctx->prof_spans[i].a, st);
+    return i;
+}
+inline void prof_close(chest_ctx* ctx, hipStream_t st, int i) {
+    if (i >= 0) (void)hipEventRecord((hipEvent_t)ctx->prof_spans[i].b, st);
+}
 // kernels that use more than 64 KiB of dynamic LDS must opt in once per device; cached in the context
 #define CHEST_LDS_OPT_IN(ctx, which, fn, bytes)                                                                    \
     do {                                                                                                       \
@@ -99,6 +131,8 @@ int launch_frames(chest_ctx* ctx, hipStream_t st, int32_t B, const chest_frame_d
                   uint64_t frame_offset, const chest_injected* inj, const chest_frame_outputs* out, void* workspace,
                   int64_t workspace_bytes);
 size_t frames_workspace_bytes(const chest_ctx* ctx, int64_t B);
+int launch_k2_slab(chest_ctx* ctx, hipStream_t st, int32_t B, const chest_frame_desc* descs, int Pmax, uint64_t seed,
+                   uint64_t frame_offset, const chest_injected& inj, const chest_frame_outputs& out, const float* workspace);
 int launch_estimate(chest_ctx* ctx, hipStream_t st, int32_t B, const float* rx4d, const float* tx_pilots,
                     int32_t pilot_stride, int32_t slot, int32_t mmse, float snr_db, float* H_est);
 int launch_at_pilots(chest_ctx* ctx, hipStream_t st, int32_t n, const float* rx, const float* tx, int32_t mmse,

@@ -20,8 +20,6 @@
 //                      interleave at 1 KiB -- tools/micro/store_wave_runs.hip).  Tap gains come in through SCALAR
 //                      loads (SGPR operands of the FMAs), tap twiddles from an LDS table built once per frame;
 //                      everything else lives in registers and the kernel only WRITES to HBM, 16 B per lane.
-#include <stdlib.h>
-
 #include "chest_device.h"
 #include "chest_internal.h"
 
@@ -34,7 +32,7 @@ __global__ void __launch_bounds__(256)
 taps_kernel(const FrameParams* __restrict__ fpp, const chest_frame_desc* __restrict__ descs, int npatterns,
             const float2* __restrict__ gram, uint64_t seed, uint64_t frame_offset,
             const float* __restrict__ inj_angle, const float* __restrict__ inj_phase, int inj_paths,
-            float* __restrict__ state, int* __restrict__ status) {
+            float* __restrict__ state, int* __restrict__ status, uint8_t* __restrict__ frame_status) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const FrameParams& fp = *fpp;                                // device-resident constant block (uniform scalar loads)
     const int b = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
@@ -42,9 +40,10 @@ taps_kernel(const FrameParams* __restrict__ fpp, const chest_frame_desc* __restr
     const chest_frame_desc fd = descs[b];
     float* rec = state + (size_t)b * frame_state_floats(S, R, T);
     if ((unsigned)fd.channel_type >= CHEST_NUM_PROFILES || (unsigned)fd.pattern_slot >= (unsigned)npatterns) {
-        if (tid == 0) { atomicExch(status, 1); rec[ST_VALID] = 0.f; }
+        if (tid == 0) { atomicExch(status, 1); rec[ST_VALID] = 0.f; if (frame_status) frame_status[b] = 1; }
         return;
     }
+    if (tid == 0 && frame_status) frame_status[b] = 0;           // K2 overwrites it if the pattern turns out unusable
     const TapProfile& prof = fp.prof[fd.channel_type];
     const int nt = prof.ntaps;
     float2* osc = (float2*)lds_raw;                              // [nt*T*R*20]
@@ -468,13 +467,7 @@ __device__ __forceinline__ void frame_body(const FrameArgs& A, int nch) {
 
 __host__ __device__ inline int frame_tw_stride(int nch) { return nch * 126 + 2; }     // float2 per tap row (even)
 
-#ifndef CHEST_K2_BOUNDS
-#define CHEST_K2_BOUNDS 1024
-#endif
-#ifndef CHEST_K2_MINWAVES
-#define CHEST_K2_MINWAVES 1
-#endif
-__global__ void __launch_bounds__(CHEST_K2_BOUNDS, CHEST_K2_MINWAVES)
+__global__ void __launch_bounds__(1024, 1)
 frame_kernel(const FrameParams* __restrict__ fpp, const chest_frame_desc* __restrict__ descs,
              const PatternDev* __restrict__ patterns, int Pmax, uint64_t seed, uint64_t frame_offset,
              const chest_injected inj, const chest_frame_outputs out, const float* __restrict__ state,
@@ -487,18 +480,7 @@ frame_kernel(const FrameParams* __restrict__ fpp, const chest_frame_desc* __rest
         // Workgroups are dealt round-robin over the 8 XCDs (b % 8 labels the blocks that share one).  Give each XCD a
         // contiguous frame range: its L2 then holds one pattern group's tables and its writes are one sequential region.
         const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, x = b & 7;
-        if (xcd_remap == 1) {
-            b = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);  // bijective for any grid size
-        } else if (xcd_remap < 0) {
-            // experiment (CHEST_FRAME_STRIDE=p, p coprime to the grid size): concurrently running workgroups are spread over the
-            // whole batch instead of forming a moving window
-            b = (int)(((long long)b * (long long)(-xcd_remap)) % nwg);
-        } else {
-            // experiment (CHEST_XCD_BLOCK=n): XCD x takes blocks of n consecutive frames round-robin; frames past the last
-            // full group of 8 blocks keep their identity mapping
-            const int n = xcd_remap, full = (nwg / (8 * n)) * (8 * n), i = b >> 3;
-            if (b < full) b = (i / n) * (8 * n) + x * n + (i % n);
-        }
+        b = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);      // bijective for any grid size
     }
     const int S = fp.S, T = fp.T, R = fp.R, nsc = fp.nsc, G = fp.G;
     const float* rec = state + (size_t)b * frame_state_floats(S, R, T);
@@ -570,13 +552,11 @@ static int launch_k2(chest_ctx* ctx, hipStream_t st, int32_t B, int nch, const c
     // Pilot symbols are staged in LDS unless that costs a resident workgroup (80 KiB each for two per CU) or does not fit.
     const size_t with = k2_lds_bytes(nch, Pmax, ctx->fp.R, true), without = k2_lds_bytes(nch, Pmax, ctx->fp.R, false);
     const bool stage = with <= 160 * 1024 && !(with > 80 * 1024 && without <= 80 * 1024);
-    size_t lds2 = stage ? with : without;
-    if (const char* pad = getenv("CHEST_K2_LDS_PAD")) lds2 += (size_t)atol(pad);      // experiment: lower the occupancy
+    const size_t lds2 = stage ? with : without;
     if (lds2 > 160 * 1024) { set_error("frame kernel needs %zu B of LDS (> 160 KiB): too many antennas or pilots", lds2); return CHEST_EINVAL; }
-    CHEST_LDS_OPT_IN(ctx, LDS_FRAME, frame_kernel, lds2);
+    CHEST_LDS_OPT_IN(ctx, LDS_FRAME_ROWS, frame_kernel, lds2);
     hipLaunchKernelGGL(frame_kernel, dim3(B), dim3(ctx->block_threads), lds2, st, ctx->d_fp, descs, ctx->d_patterns,
-                       Pmax, seed, frame_offset, inj, out, workspace, nch, getenv("CHEST_NO_XCD_REMAP") ? 0 : (getenv("CHEST_FRAME_STRIDE") ? -atoi(getenv("CHEST_FRAME_STRIDE")) : (getenv("CHEST_XCD_BLOCK") ? atoi(getenv("CHEST_XCD_BLOCK")) : 1)),
-                       ctx->d_status, stage ? 1 : 0);
+                       Pmax, seed, frame_offset, inj, out, workspace, nch, 1, ctx->d_status, stage ? 1 : 0);
     return CHEST_OK;
 }
 
@@ -604,17 +584,21 @@ int launch_frames(chest_ctx* ctx, hipStream_t st, int32_t B, const chest_frame_d
         set_error("injected u_angle/u_phase and n_re/n_im must be given in pairs");
         return CHEST_EINVAL;
     }
-    const int nch = (fp.nsc + 125) / 126;
     // optional per-kernel timing (chest_profile_begin): events on the launch stream around each of the two kernels
-    hipEvent_t* pev = nullptr;
-    if ((size_t)(ctx->prof_used + 1) * 3 <= ctx->prof_events.size()) pev = (hipEvent_t*)&ctx->prof_events[(size_t)ctx->prof_used * 3];
-    if (pev) CHEST_HIP(hipEventRecord(pev[0], st));
+    const int sp1 = prof_open(ctx, st, CHEST_K_TAPS);
     hipLaunchKernelGGL(taps_kernel, dim3(B), dim3(256), lds1, st, ctx->d_fp, descs, (int)ctx->patterns.size(), ctx->d_gram, seed,
-                       frame_offset, inj_v.u_angle, inj_v.u_phase, inj_v.inj_paths, (float*)workspace, ctx->d_status);
-    if (pev) CHEST_HIP(hipEventRecord(pev[1], st));
-    const int rc = launch_k2(ctx, st, B, nch, descs, Pmax, seed, frame_offset, inj_v, *out, (const float*)workspace);
+                       frame_offset, inj_v.u_angle, inj_v.u_phase, inj_v.inj_paths, (float*)workspace, ctx->d_status, out->frame_status);
+    prof_close(ctx, st, sp1);
+    const int sp2 = prof_open(ctx, st, CHEST_K_FRAME);
+    int rc;
+    if (ctx->tune_legacy_rows) {
+        if (out->pilot_mask_f32 != nullptr) { set_error("pilot_mask_f32 is not available on the legacy row-store path"); return CHEST_EINVAL; }
+        rc = launch_k2(ctx, st, B, (fp.nsc + 125) / 126, descs, Pmax, seed, frame_offset, inj_v, *out, (const float*)workspace);
+    } else {
+        rc = launch_k2_slab(ctx, st, B, descs, Pmax, seed, frame_offset, inj_v, *out, (const float*)workspace);
+    }
     if (rc != CHEST_OK) return rc;
-    if (pev) { CHEST_HIP(hipEventRecord(pev[2], st)); ++ctx->prof_used; }
+    prof_close(ctx, st, sp2);
     CHEST_HIP(hipGetLastError());
     return CHEST_OK;
 }

@@ -584,6 +584,7 @@ int chest_mmse_full_prepare(chest_ctx* ctx, void* stream, int32_t P, const doubl
                   (long long)chest_mmse_full_workspace_bytes(P));
         return CHEST_EINVAL;
     }
+    CHEST_GUARD(ctx);
     hipStream_t st = (hipStream_t)stream;
     const double s2 = 1.0 / pow(10.0, (double)snr_db / 10.0);              // (:174-175)
     cdd* A = (cdd*)workspace;
@@ -619,6 +620,7 @@ int chest_mmse_full_apply(chest_ctx* ctx, void* stream, int32_t B, const float* 
         set_error("pattern slot %d is not set or has no plan", slot);
         return CHEST_ESTATE;
     }
+    CHEST_GUARD(ctx);
     hipStream_t st = (hipStream_t)stream;
     const auto& f = ctx->fp;
     const PatternDev& pd = ctx->patterns[slot].dev;
@@ -669,6 +671,7 @@ int chest_mmse_full_apply_pilots(chest_ctx* ctx, void* stream, int32_t B, const 
         set_error("pattern slot %d is not set or has no plan", slot);
         return CHEST_ESTATE;
     }
+    CHEST_GUARD(ctx);
     hipStream_t st = (hipStream_t)stream;
     const auto& f = ctx->fp;
     const PatternDev& pd = ctx->patterns[slot].dev;
@@ -678,15 +681,21 @@ int chest_mmse_full_apply_pilots(chest_ctx* ctx, void* stream, int32_t B, const 
     float2* h_in = (float2*)h_scratch;
     float2* h_out = h_in + (size_t)Mpad * Ppad;
     float2* w_packed = h_out + (size_t)M * Ppad;
+    const int sp_pack = prof_open(ctx, st, CHEST_K_PACK);
     hipLaunchKernelGGL(pack_h_kernel, dim3(Mpad), dim3(256), 0, st, M, P, h_ls_stride, Ppad, (const float2*)h_ls_pilots, h_in);
     hipLaunchKernelGGL(pack_w_kernel, dim3(Npad), dim3(256), 0, st, P, Ppad, (const float2*)W, w_packed);
+    prof_close(ctx, st, sp_pack);
     CHEST_LDS_OPT_IN(ctx, LDS_GEMM3M, cgemm_w_kernel_3m, T3_LDS_BYTES);
+    const int sp_gemm = prof_open(ctx, st, CHEST_K_GEMM);
     hipLaunchKernelGGL(cgemm_w_kernel_3m, dim3(Npad / T2_N, Mpad / T2_M), dim3(256), T3_LDS_BYTES, st, P, Ppad, M, Ppad,
                        (const float2*)w_packed, h_in, h_out);
+    prof_close(ctx, st, sp_gemm);
     const size_t lds = (size_t)P * sizeof(float2);
     CHEST_LDS_OPT_IN(ctx, LDS_INTERP, interp_from_pilots_kernel, lds);
+    const int sp_int = prof_open(ctx, st, CHEST_K_INTERP);
     hipLaunchKernelGGL(interp_from_pilots_kernel, dim3(M), dim3(256), lds, st, f.S, f.R, f.T, f.nsc, Ppad, ctx->d_patterns,
                        slot, h_out, (float2*)H_est, 1);
+    prof_close(ctx, st, sp_int);
     CHEST_HIP(hipGetLastError());
     return CHEST_OK;
 }
@@ -708,6 +717,7 @@ int chest_estimate_dense(chest_ctx* ctx, void* stream, int32_t B, const float* r
         set_error("pattern slot %d is not set", slot);
         return CHEST_ESTATE;
     }
+    CHEST_GUARD(ctx);
     hipStream_t st = (hipStream_t)stream;
     const auto& f = ctx->fp;
     const PatternDev& pd = ctx->patterns[slot].dev;

@@ -28,6 +28,8 @@ from . import interp_plan
 
 DESC_DTYPE = np.dtype([("channel_type", "<i4"), ("doppler_hz", "<f4"), ("snr_db", "<f4"), ("pattern_slot", "<i4")])
 ALL_OUTPUTS = ("tx", "rx", "H", "H_ls", "H_mmse", "pilot_symbols", "pilot_mask", "metrics")
+# further outputs on request: "h_ls_pilots" (input of mmse_full_apply_pilots), "pilot_mask_f32" (the dataset schema's float32
+# mask), "frame_status" (per-frame uint8: 0 ok / 1 bad descriptor / 2 no plan)
 
 
 @dataclass(frozen=True)
@@ -202,10 +204,25 @@ class Engine:
         N.check(N.lib().chest_profile_begin(self._h, int(capacity)), "chest_profile_begin")
 
     def profile_read(self):
-        """(taps_kernel ms, frame_kernel ms, calls averaged); synchronises."""
+        """(taps_kernel ms, frame_kernel ms, calls averaged); synchronises and re-arms."""
         a, b, n = C.c_float(), C.c_float(), C.c_int32()
         N.check(N.lib().chest_profile_read(self._h, C.byref(a), C.byref(b), C.byref(n)), "chest_profile_read")
         return a.value, b.value, n.value
+
+    def profile_read_all(self):
+        """{kernel name: average ms per launch} for every kernel kind recorded since profile_begin; synchronises, re-arms."""
+        res = {}
+        for name, kid in N.KERNEL_IDS.items():
+            ms, n = C.c_float(), C.c_int32()
+            N.check(N.lib().chest_profile_read_kernel(self._h, kid, C.byref(ms), C.byref(n)), "chest_profile_read_kernel")
+            if n.value:
+                res[name] = ms.value
+        self.profile_read()
+        return res
+
+    def tune(self, key: str, value: int):
+        """Experiment knobs of the library (tools only): 'frame_rx_group', 'frame_legacy_rows'."""
+        N.check(N.lib().chest_tune(self._h, key.encode(), int(value)), "chest_tune")
 
     # ---- helpers ----------------------------------------------------------------------------------
     def _stream(self):
@@ -245,7 +262,8 @@ class Engine:
                   "H": ((B, S, R, T, nsc), torch.complex64), "H_ls": ((B, S, R, T, nsc), torch.complex64),
                   "H_mmse": ((B, S, R, T, nsc), torch.complex64), "pilot_symbols": ((B, pmax), torch.complex64),
                   "pilot_mask": ((B, S, nsc), torch.uint8), "metrics": ((B, N.NUM_METRICS), torch.float32),
-                  "h_ls_pilots": ((B, R, (pmax + 15) // 16 * 16), torch.complex64)}
+                  "h_ls_pilots": ((B, R, (pmax + 15) // 16 * 16), torch.complex64),
+                  "pilot_mask_f32": ((B, S, nsc), torch.float32), "frame_status": ((B,), torch.uint8)}
         res = {} if out is None else dict(out)
         fo = N.FrameOutputs()
         fo.pilot_stride = pmax
@@ -315,7 +333,7 @@ class Engine:
         return dev[:nbytes]
 
     # ---- output placement ---------------------------------------------------------------------------------
-    PLACEMENT_GROUPS = (("tx", "rx", "H", "pilot_symbols", "pilot_mask"), ("H_ls", "H_mmse"))
+    PLACEMENT_GROUPS = (("tx", "rx", "H", "pilot_symbols", "pilot_mask", "pilot_mask_f32"), ("H_ls", "H_mmse"))
 
     def place_outputs(self, descs, outputs=ALL_OUTPUTS, seed=0, tries=4):
         """Allocate the output tensors for repeated ``run_frames(..., out=...)`` calls, choosing WHERE they live.

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define CHEST_ABI_VERSION 1
+#define CHEST_ABI_VERSION 2
 
 #define CHEST_OK 0
 #define CHEST_EINVAL (-1)   /* bad argument / unsupported shape */
@@ -97,7 +97,17 @@ typedef struct chest_frame_outputs {
     float* h_ls_pilots;          /* [B][R][h_ls_stride] c64: LS estimates at the pilots, y_p / (x_p + 1e-12), in pilot order
                                   * (what LSEstimator.estimate_at_pilots yields for every tx of that rx, quirk Q9); entries
                                   * P..h_ls_stride-1 are written as 0.  Input of chest_mmse_full_apply_pilots. */
+    float* pilot_mask_f32;       /* [B][G] float32 0/1: 'pilot_mask' in the dataset schema
+                                  * (run_phase3_dataset_generation.py:139 stores it as float32) */
+    uint8_t* frame_status;       /* [B]: 0 = frame produced, CHEST_FRAME_BAD_DESC = channel_type / pattern_slot invalid or the
+                                  * slot never set, CHEST_FRAME_NO_PLAN = estimates requested for a pattern without a plan.
+                                  * A failed frame's outputs are left untouched and the batch continues, as the reference's
+                                  * dataset loop skips a failed sample (src/dataset_generator.py:120-125). */
 } chest_frame_outputs;
+
+#define CHEST_FRAME_OK 0
+#define CHEST_FRAME_BAD_DESC 1
+#define CHEST_FRAME_NO_PLAN 2
 
 /* metrics[b][*] (float32) */
 #define CHEST_M_SUM_H2 0         /* sum |H|^2 over (S,R,T,nsc) */
@@ -147,12 +157,26 @@ int chest_pattern_num_pilots(chest_ctx* ctx, int32_t slot);
  * plan (2); reading it synchronises the device and clears it. HOST out. */
 int chest_get_status(chest_ctx* ctx, int32_t* status);
 
-/* Per-kernel timing of chest_frames_run (measurement aid): after chest_profile_begin(ctx, n) the next n calls record
- * HIP events on their launch stream before the taps kernel, before the frame kernel and after it;
- * chest_profile_read synchronises on them, returns the average duration of each kernel in milliseconds and the number
- * of calls averaged, and re-arms.  chest_profile_begin(ctx, 0) turns it off.  Do not use while capturing a graph. */
+/* Per-kernel timing (measurement aid): after chest_profile_begin(ctx, n) the library records HIP event pairs on the
+ * launch stream around each kernel (group) of the next launch-group calls, up to 8*n pairs, tagged with a CHEST_K_* id.
+ * chest_profile_read_kernel synchronises on the recorded pairs of one id and returns their average duration in
+ * milliseconds and their number; chest_profile_read does that for the taps and the frame kernel and then re-arms
+ * (forgets all recorded pairs).  chest_profile_begin(ctx, 0) turns it off.  Do not use while capturing a graph. */
+#define CHEST_K_TAPS 0           /* taps_kernel        (chest_frames_run) */
+#define CHEST_K_FRAME 1          /* frame kernel       (chest_frames_run) */
+#define CHEST_K_PACK 2           /* operand packing    (chest_mmse_full_apply*, chest_estimate_dense) */
+#define CHEST_K_GEMM 3           /* MFMA GEMM          (chest_mmse_full_apply*, chest_estimate_dense) */
+#define CHEST_K_INTERP 4         /* interpolation from pilot values (chest_mmse_full_apply*) */
+#define CHEST_K_PLAN 5           /* interpolation-plan construction (chest_patterns_build) */
+#define CHEST_NUM_KERNEL_IDS 6
 int chest_profile_begin(chest_ctx* ctx, int32_t capacity);
 int chest_profile_read(chest_ctx* ctx, float* taps_ms, float* frame_ms, int32_t* count);
+int chest_profile_read_kernel(chest_ctx* ctx, int32_t kernel_id, float* ms, int32_t* count);
+
+/* Tuning knobs for experiments (tools/ only; the launch path reads nothing from the environment).  Keys:
+ *   "frame_rx_group"   rx antennas per LDS slab unit of the frame kernel (0 = chosen from the LDS budget)
+ *   "frame_legacy_rows" 1 = the previous row-store frame kernel, for in-process A/B */
+int chest_tune(chest_ctx* ctx, const char* key, int32_t value);
 
 /* ---- launch group (asynchronous, no allocation) -------------------------------------------- */
 

@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""In-process A/B of the frame kernel's write paths on ONE set of output buffers (first allocation, no placement probing):
+slab path (default) with each admissible rx-group size against the legacy row-store path.  Prints the library's own
+HIP-event kernel times (median of --reps launches, interleaved round-robin so that clock / thermal drift hits all alike).
+
+    python tools/ab_paths.py [--workload cfg2|cfg3|cfg1] [--frames N] [--reps 9] [--sets 2]
+"""
+import argparse
+import importlib
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+PKG = "channel-estimation-in-5g-network_amd"
+SHAPES = {"cfg2": (2, 2, "EVA", 111.1, 10000), "cfg3": (4, 4, "ETU", 370.4, 6250), "cfg1": (1, 1, "EPA", 5.56, 10000)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", default="cfg2", choices=sorted(SHAPES))
+    ap.add_argument("--frames", type=int, default=0)
+    ap.add_argument("--reps", type=int, default=9)
+    ap.add_argument("--sets", type=int, default=2, help="independently allocated output sets (placement spread)")
+    ap.add_argument("--no-legacy", action="store_true")
+    args = ap.parse_args()
+    import torch
+    E = importlib.import_module(PKG + ".engine")
+    T, R, ct, fd, F = SHAPES[args.workload]
+    F = args.frames or F
+    geom = E.Geometry(num_tx=T, num_rx=R)
+    eng = E.Engine(geom, 0)
+    G = geom.grid
+    P = int(G * 0.1)
+    slots = []
+    for g in range((F + 1023) // 1024):
+        perm = np.arange(G); np.random.RandomState(2024 + g).shuffle(perm)
+        slots.append(eng.pattern_slot(np.sort(perm[:P]), "linear"))
+    descs = E.make_descs(ct, fd, 10.0, np.asarray(slots, np.int32)[np.arange(F) // 1024], n=F)
+    d_dev = torch.from_numpy(descs.view(np.uint8).copy()).to(eng.device)
+    names = ["tx", "rx", "H", "H_ls", "H_mmse", "pilot_symbols", "pilot_mask"]
+    sets = [eng.run_frames(d_dev, seed=1, outputs=names) for _ in range(args.sets)]
+    variants = [("slab rg=%d" % rg, {"frame_legacy_rows": 0, "frame_rx_group": rg}) for rg in range(1, R + 1) if R % rg == 0]
+    if not args.no_legacy:
+        variants.append(("legacy rows", {"frame_legacy_rows": 1, "frame_rx_group": 0}))
+    bytes_frame = 8 * G * (T + R + 3 * R * T) + G + 8 * P
+    times = {(v, i): [] for v, _ in variants for i in range(args.sets)}
+    for rep in range(args.reps + 1):
+        for name, knobs in variants:
+            for k, v in knobs.items():
+                eng.tune(k, v)
+            for i, out in enumerate(sets):
+                eng.profile_begin(1)
+                eng.run_frames(d_dev, seed=1, outputs=names, out=out, check=False)
+                ms = eng.profile_read()[1]
+                if rep:
+                    times[(name, i)].append(ms)
+    eng.check_status()
+    for name, _ in variants:
+        row = []
+        for i in range(args.sets):
+            m = float(np.median(times[(name, i)]))
+            row.append(f"set{i}: {m:.3f} ms = {bytes_frame * F / m / 1e9:.2f} TB/s ({bytes_frame * F / m / 1e9 / 8.0:.1%})")
+        print(f"{args.workload} {F} frames  {name:12s}  " + "   ".join(row), flush=True)
+
+
+if __name__ == "__main__":
+    main()
