@@ -64,6 +64,8 @@ static int build_tables(chest_ctx* ctx) {
             tp.delay[tp.ntaps] = ctx->delay_samples[ty][l];
             tp.path[tp.ntaps] = l;
             tp.amp[tp.ntaps] = (float)(sqrt(ctx->powers_linear[ty][l]) / sqrt(2.0 * CHEST_NUM_OSC));   // (:104, :124)
+            const double sa = -2.0 * M_PI * (double)ctx->delay_samples[ty][l] / (double)fp.N;
+            tp.step[tp.ntaps][0] = (float)cos(sa); tp.step[tp.ntaps][1] = (float)sin(sa);
             ++tp.ntaps;
         }
     }
@@ -83,9 +85,6 @@ static int build_tables(chest_ctx* ctx) {
                 ctx->gram_host[((size_t)ty * KT + d1) * KT + d2] = make_float2((float)re, (float)im);
             }
     }
-    // frame kernel: wave <-> OFDM symbol; two symbols per wave measured best on MI355X (7 waves for S = 14)
-    const int nwaves = (fp.S + 1) / 2;
-    ctx->block_threads = (nwaves > 16 ? 16 : nwaves) * 64;
     return CHEST_OK;
 }
 
@@ -405,7 +404,7 @@ int chest_profile_read(chest_ctx* ctx, float* taps_ms, float* frame_ms, int32_t*
 int chest_tune(chest_ctx* ctx, const char* key, int32_t value) {
     if (!ctx || !key) { set_error("chest_tune: null argument"); return CHEST_EINVAL; }
     if (strcmp(key, "frame_rx_group") == 0) { ctx->tune_rx_group = value; return CHEST_OK; }
-    if (strcmp(key, "frame_legacy_rows") == 0) { ctx->tune_legacy_rows = value != 0; return CHEST_OK; }
+    if (strcmp(key, "frame_min_waves") == 0) { ctx->tune_min_waves = value; return CHEST_OK; }
     set_error("chest_tune: unknown key '%s'", key);
     return CHEST_EINVAL;
 }

@@ -12,13 +12,16 @@ namespace chest {
 constexpr int KT = 9;   // max EFFECTIVE taps (distinct delays) a kernel keeps in registers; EPA 5, EVA 8, ETU 9
 constexpr int KTS = 10;  // float2 stride of one tap vector in the frame-state record (80-B, 16-B aligned rows)
 
-// Frame-state record written by taps_kernel and read (scalar loads) by frame_kernel:
-//   float scal[ST_SCAL]; float2 c[S*R*T][KTS]; float2 csum[S*R][KTS]
+// Frame-state record written by taps_kernel and read (scalar loads) by the frame kernel:
+//   float scal[ST_SCAL]; float2 c[S][KTS][R][T]; float2 csum[S][KTS][R]
+// Tap-major inside a symbol: the gains of ONE tap for all antenna pairs are contiguous (one s_load per tap).
 constexpr int ST_SCAL = 8;
 enum { ST_NOISE_STD = 0, ST_SIGMA2 = 1, ST_SIGNAL_POWER = 2, ST_SUM_H2 = 3, ST_SUM_VAR = 4, ST_VALID = 5 };
 __host__ __device__ inline size_t frame_state_floats(int S, int R, int T) {
     return (size_t)ST_SCAL + 2 * (size_t)KTS * ((size_t)S * R * T + (size_t)S * R);
 }
+__host__ __device__ inline int state_c_index(int s, int d, int r, int t, int R, int T) { return ((s * KTS + d) * R + r) * T + t; }
+__host__ __device__ inline int state_csum_index(int s, int d, int r, int R) { return (s * KTS + d) * R + r; }
 
 // Tap profile after the delay-collision overwrite (quirk Q1, src/channel_simulator.py:125):
 // one entry per distinct delay, carrying the LAST path that rounds to it.
@@ -29,6 +32,7 @@ struct TapProfile {
     int32_t delay[KT];
     int32_t path[KT];
     float amp[KT];                 // sqrt(p_l) / sqrt(2*20)
+    float step[KT][2];             // exp(-2 pi j delay/N): twiddle ratio of two adjacent used bins on the same side of DC
 };
 
 struct FrameParams {               // passed by value (kernarg segment -> scalar loads)
@@ -62,7 +66,6 @@ struct chest_ctx {
     std::vector<float2> gram_host;
     chest::PatternDev* d_patterns = nullptr;   // device mirror, capacity pattern_cap
     int32_t pattern_cap = 0;
-    int32_t block_threads = 0;     // workgroup size of the per-frame kernels
     int32_t* d_status = nullptr;   // device error word (bad descriptor seen by a kernel)
     float2* d_twiddle = nullptr;   // FFT twiddles exp(-2 pi j n/N), n < N (power-of-two N only)
     float2* d_gram = nullptr;      // [3][KT][KT] Gram matrices of the tap twiddles over the used bins
@@ -70,10 +73,10 @@ struct chest_ctx {
     struct ProfSpan { int32_t id; void* a; void* b; };     // hipEvent_t pair around one kernel (group) of kind `id` (CHEST_K_*)
     std::vector<ProfSpan> prof_spans;     // pool created by chest_profile_begin; launches never allocate
     int32_t prof_used = 0;                // spans recorded since chest_profile_begin / the last chest_profile_read
-    size_t lds_opt_in[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // largest dynamic-LDS size already opted in per kernel (per context = per device)
+    size_t lds_opt_in[16] = {};   // largest dynamic-LDS size already opted in per kernel (per context = per device)
     // chest_tune (tools / experiments only; nothing on the launch path reads the environment)
     int32_t tune_rx_group = 0;            // rx antennas per slab unit of the frame kernel (0 = chosen from the LDS budget)
-    int32_t tune_legacy_rows = 0;         // 1 = previous row-store frame kernel (kept for in-process A/B)
+    int32_t tune_min_waves = 0;           // 4 = the 128-VGPR instantiation of the 2x2 frame kernel (two workgroups per CU), for A/B
 };
 
 namespace chest {
@@ -89,7 +92,7 @@ void set_error(const char* fmt, ...);
     } while (0)
 
 enum { LDS_TAPS = 0, LDS_FRAME = 1, LDS_ESTIMATE = 2, LDS_INTERP = 3, LDS_GEMM = 4, LDS_GEMM3M = 5, LDS_FRAME_640 = 6,
-       LDS_FRAME_1024 = 7, LDS_FRAME_ROWS = 8, LDS_DELAUNAY = 9 };
+       LDS_FRAME_1024 = 7, LDS_FRAME_ROWS = 8, LDS_DELAUNAY = 9, LDS_FRAME_44 = 10, LDS_FRAME_11 = 11, LDS_FRAME_GEN = 12, LDS_FRAME_W5 = 13 };
 
 // RAII: make the context's device current for the duration of an entry point and restore the caller's afterwards
 struct DeviceGuard {

@@ -36,18 +36,43 @@ __device__ __forceinline__ void st8(float2* p, float2 a) {
 
 // Copy LDS segment l[0..n) to global g[0..n) (float2 elements; g and l wave-uniform with equal address mod 16).
 // Store q covers the 1 KiB window of 128-B lines [q*128 - head, q*128 - head + 128) in element units, head = elements
-// between the enclosing line start and g.  Stores q0, q0 + qstep, ... are this wave's.  Returns the number of stores.
+// between the enclosing line start and g.  Stores q0, q0 + qstep, ... are this wave's (0 <= q0 < qstep).  Returns the
+// number of stores of the segment.
+__device__ __forceinline__ void seg_store_edge(float2* __restrict__ g, const float2* __restrict__ l, int n, int e) {
+    if (e >= 0 && e + 1 < n) st16(g + e, *(const float4*)(l + e));
+    else if (e == -1) st8(g, l[0]);                           // odd head: element 0 sits alone in its 16-B slot
+    else if (e >= 0 && e == n - 1) st8(g + e, l[e]);
+}
 __device__ __forceinline__ int seg_store(float2* __restrict__ g, const float2* __restrict__ l, int n, int q0, int qstep, int lane) {
     const int head = (int)(((uintptr_t)g & 127u) >> 3);
     const int nst = (head + n + 127) >> 7;
-    for (int q = q0; q < nst; q += qstep) {
-        const int e = (q << 7) - head + 2 * lane;
-        if (e >= 0 && e + 1 < n) st16(g + e, *(const float4*)(l + e));
-        else if (e == -1) st8(g, l[0]);                       // odd head: element 0 sits alone in its 16-B slot
-        else if (e >= 0 && e == n - 1) st8(g + e, l[e]);
+    const int off = 2 * lane - head;
+    if (q0 == 0) seg_store_edge(g, l, n, off);                                    // first window: may start before g
+    if (nst > 1 && (nst - 1 - q0) % qstep == 0 && nst - 1 >= q0) seg_store_edge(g, l, n, ((nst - 1) << 7) + off);   // last window: may end after g + n
+    // interior windows are whole: no per-lane conditions; two in flight per iteration (both LDS reads before the stores)
+    int q = q0 == 0 ? qstep : q0;
+    for (; q + qstep < nst - 1; q += 2 * qstep) {
+        const int e0 = (q << 7) + off, e1 = ((q + qstep) << 7) + off;
+        const float4 a = *(const float4*)(l + e0), b = *(const float4*)(l + e1);
+        st16(g + e0, a);
+        st16(g + e1, b);
     }
+    if (q < nst - 1) { const int e0 = (q << 7) + off; st16(g + e0, *(const float4*)(l + e0)); }
     return nst;
 }
+
+// Diagnostic build only (-DCHEST_STAMPS, tools/stamps.py): per-wave cycle sums of the unit's segments, written to a buffer of
+// their own; no stamp executes in the shipped library.
+#ifdef CHEST_STAMPS
+__device__ unsigned long long* g_stamp_buf = nullptr;       // [B][16 waves][16 slots]
+#define STAMP(t) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define STAMP_DECL unsigned long long st_a = 0, st_b = 0, st_sum[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
+#define STAMP_ADD(i) do { STAMP(st_b); st_sum[i] += st_b - st_a; st_a = st_b; } while (0)
+#else
+#define STAMP(t) do { } while (0)
+#define STAMP_DECL do { } while (0)
+#define STAMP_ADD(i) do { } while (0)
+#endif
 
 struct SlabArgs {
     const FrameParams* fp;
@@ -74,38 +99,59 @@ __host__ __device__ inline int slab_elems(int T, int RG, int nsc) {
     return w > e ? w : e;
 }
 
-template <int NT>
+// TT / RR / RGT > 0: compile-time antenna counts and rx-group size.  Loops unroll; a unit's rows are accumulated in
+// registers TAP-OUTER (one scalar load brings a tap's gains for all antenna pairs of the unit, so coefficient SGPRs are
+// streamed instead of hoisted row by row), the odd subcarrier's twiddle is the even one's times the tap's uniform step
+// exp(-2 pi j delay/N) (needs an even number of used bins below DC: no pair straddles it; the launcher checks), and both
+// barriers of a unit sit back to back behind the long compute stretch.  0 = run-time values: full twiddle registers,
+// rows written to the slab as they are produced.
+template <int NT, int TT, int RR, int RGT, bool INJ>
 __device__ __forceinline__ void slab_body(const SlabArgs& A) {
     const FrameParams& fp = *A.fp;
     const PatternDev& pat = *A.pat;
     const chest_injected& inj = *A.inj;
     const chest_frame_outputs& out = *A.out;
-    const int S = fp.S, G = fp.G, P = pat.P, b = A.b, T = fp.T, R = fp.R, RG = A.RG;
+    constexpr bool STAGED = TT > 0 && RR > 0 && RGT > 0;
+    const int S = fp.S, G = fp.G, P = pat.P, b = A.b;
+    const int T = TT > 0 ? TT : fp.T, R = RR > 0 ? RR : fp.R, RG = RGT > 0 ? RGT : A.RG;
     const int nsc = fp.nsc;
     const int tid = threadIdx.x, lane = tid & 63, nwave = blockDim.x >> 6;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const unsigned npair = ((unsigned)nsc + 1) >> 1;
-    const int k0 = 2 * tid, k1 = k0 + 1;
-    const bool v0 = k0 < nsc, v1 = k1 < nsc;
-    const int kc0 = v0 ? k0 : nsc - 1, kc1 = v1 ? k1 : nsc - 1;
+    // subcarrier pairs are dealt evenly to the waves (599 subcarriers: 60 pairs on each of 5 waves) so that no wave of
+    // the workgroup is the straggler at the unit barriers
+    const int npair = (nsc + 1) >> 1;
+    const int ppw = (npair + nwave - 1) / nwave;
+    const int pr = wave * ppw + lane;
+    const bool act = lane < ppw && pr < npair;
+    const int k0 = 2 * pr, k1 = k0 + 1;
+    const bool v1 = act && k1 < nsc;
+    const bool tailw = __builtin_amdgcn_readfirstlane((int)((nsc & 1) && wave == (npair - 1) / ppw));   // the wave that owns the odd last subcarrier
+    const int kc0 = act ? k0 : nsc - 1, kc1 = v1 ? k1 : nsc - 1;
     const float noise_std = A.rec[ST_NOISE_STD];
     float2* __restrict__ hp = A.hp;
     float2* __restrict__ slab = A.slab;
     float2* __restrict__ txb = out.tx ? (float2*)out.tx + (size_t)b * S * T * nsc : nullptr;
     float2* __restrict__ rxb = out.rx ? (float2*)out.rx + (size_t)b * S * R * nsc : nullptr;
     float2* __restrict__ Hb = out.H ? (float2*)out.H + (size_t)b * S * R * T * nsc : nullptr;
-    float2* __restrict__ Lb = out.H_ls ? (float2*)out.H_ls + (size_t)b * S * R * T * nsc : nullptr;
-    float2* __restrict__ Mb = out.H_mmse ? (float2*)out.H_mmse + (size_t)b * S * R * T * nsc : nullptr;
-    const float* __restrict__ usym = inj.u_sym ? inj.u_sym + (size_t)b * G : nullptr;
-    const float* __restrict__ nre = inj.n_re ? inj.n_re + (size_t)b * S * R * nsc : nullptr;
-    const float* __restrict__ nim = inj.n_im ? inj.n_im + (size_t)b * S * R * nsc : nullptr;
+    // INJ == false: the device-RNG instantiation carries no injected-input pointers or branches at all
+    const float* __restrict__ usym = (INJ && inj.u_sym) ? inj.u_sym + (size_t)b * G : nullptr;
+    const float* __restrict__ nre = (INJ && inj.n_re) ? inj.n_re + (size_t)b * S * R * nsc : nullptr;
+    const float* __restrict__ nim = (INJ && inj.n_im) ? inj.n_im + (size_t)b * S * R * nsc : nullptr;
     const uint16_t* __restrict__ slots = pat.slot;
     // parity (element offset & 1) of the frame's first element in each tensor; 16-B-aligned tensor bases (host-checked)
     const int par_tx = (int)(((size_t)b * S * T * nsc) & 1), par_rx = (int)(((size_t)b * S * R * nsc) & 1),
               par_h = (int)(((size_t)b * S * R * T * nsc) & 1);
+    // one row of a slab segment: both subcarriers of the pair; only the wave holding the odd last subcarrier needs a
+    // per-lane condition (callers are inside `if (act)`)
+    auto put = [&](float2* __restrict__ row, float2 a, float2 b2) {
+        row[k0] = a;
+        if (!tailw) row[k1] = b2;
+        else if (v1) row[k1] = b2;
+    };
 
-    // ---- tap twiddles of this thread's two subcarriers: registers for the whole frame ----------------------------
-    float4 w[NT];
+    // ---- tap twiddles exp(-2 pi j kappa_k d / N) of this thread's subcarriers: registers for the whole frame ---------
+    constexpr int NW = STAGED ? 1 : 2;                           // STAGED keeps the even subcarrier's only
+    float2 w[NT][NW];
     {
         const float invN = 1.0f / (float)fp.N;
         const int half = fp.half;
@@ -113,14 +159,32 @@ __device__ __forceinline__ void slab_body(const SlabArgs& A) {
 #pragma unroll
         for (int d = 0; d < NT; ++d) {
             const int dl = A.prof->delay[d];
-            const float2 e0 = cis_turns((float)(ka * dl) * invN), e1 = cis_turns((float)(kb * dl) * invN);   // |kappa*delay| < 2^24: exact
-            w[d] = make_float4(e0.x, -e0.y, e1.x, -e1.y);
+            const float2 e0 = cis_turns((float)(ka * dl) * invN);                // |kappa*delay| < 2^24: exact
+            w[d][0] = make_float2(e0.x, -e0.y);
+            if constexpr (!STAGED) { const float2 e1 = cis_turns((float)(kb * dl) * invN); w[d][NW - 1] = make_float2(e1.x, -e1.y); }
         }
     }
+    auto w_odd = [&](int d) -> float2 {                          // twiddle of the pair's odd subcarrier
+        if constexpr (STAGED) {
+            float2 we = w[d][0];
+            asm volatile("" : "+v"(we.x), "+v"(we.y));           // keeps the product inside the loop: hoisted, it would cost the
+            return cmul(we, make_float2(A.prof->step[d][0], A.prof->step[d][1]));   // 2*NT registers this form exists to save
+        } else return w[d][NW - 1];
+    };
 
     const int seg_tx = 0, seg_h = slab_seg(T, nsc), seg_rx = seg_h + slab_seg(RG * T, nsc);
     const int ngroups = R / RG;
     bool first_unit = true;
+    // Store-out crew.  A workgroup of 4n+1 waves puts two of its waves on one SIMD; the younger of them loses the issue
+    // arbitration and is the straggler of every compute stretch (stamps: +40 % on the 5th wave).  It is excused from the
+    // store-out: after the "slab complete" barrier it goes straight to the next unit's compute while the others stream the
+    // slab, which hands it a head start the length of the store-out.
+    // (Only where a unit carries enough synthesis for that to pay: with one or two rows per unit the stores are the
+    // longer leg and every wave is needed for them.)
+    const int nstw = (nwave > 4 && (nwave & 3) == 1 && RG * T >= 4) ? nwave - 1 : nwave;
+    const bool storer = wave < nstw;
+    STAMP_DECL;
+    STAMP(st_a);
 
     // ---- phase W: per unit (symbol, rx group) assemble tx / H / rx rows in the slab, then stream them out ------------
     uint32_t sl0 = slots[kc0], sl1 = slots[kc1];
@@ -131,12 +195,13 @@ __device__ __forceinline__ void slab_body(const SlabArgs& A) {
         if (usym != nullptr) {
             u0 = usym[s0]; u1 = usym[s1];
         } else {
-            const u32x4 z = draw(A.key, STREAM_SYM, (uint32_t)s * npair + (uint32_t)tid);
+            const u32x4 z = draw(A.key, STREAM_SYM, (uint32_t)(s * npair + pr));
             u0 = u01(z.x); u1 = u01(z.y);
         }
         const float2 x0 = cis_unit(__builtin_amdgcn_fractf(u0));                 // exp(j 2pi u) (:395,:399)
         const float2 x1 = cis_unit(__builtin_amdgcn_fractf(u1));
-        const bool p0 = v0 && s0 < (unsigned)P, p1 = v1 && s1 < (unsigned)P;
+        const bool p0 = act && s0 < (unsigned)P, p1 = v1 && s1 < (unsigned)P;
+        const float2* __restrict__ cs = A.c_g + (size_t)s * KTS * R * T;         // this symbol's gains [tap][r][t]
         for (int rg = 0; rg < ngroups; ++rg) {
             const int r0 = rg * RG;
             // global spans of this unit (element offsets inside the frame) and their parities
@@ -145,64 +210,125 @@ __device__ __forceinline__ void slab_body(const SlabArgs& A) {
             float2* __restrict__ l_tx = slab + seg_tx + ((par_tx + e_tx) & 1);
             float2* __restrict__ l_h = slab + seg_h + ((par_h + e_h) & 1);
             float2* __restrict__ l_rx = slab + seg_rx + ((par_rx + e_rx) & 1);
-            if (!first_unit) __syncthreads();                                    // previous unit's store-out has read the slab
-            first_unit = false;
-            if (rg == 0 && txb != nullptr) {
-                for (int t = 0; t < T; ++t) {
-                    if (v0) l_tx[t * nsc + k0] = x0;
-                    if (v1) l_tx[t * nsc + k1] = x1;
-                }
-            }
-            for (int rr = 0; rr < RG; ++rr) {
-                const int r = r0 + rr;
-                // sum_t H_t is always accumulated from the per-tx rows, whether or not H is stored, so that rx / H_ls /
-                // H_mmse are bit-identical for every choice of requested outputs.
-                float2 hs0 = make_float2(0.f, 0.f), hs1 = make_float2(0.f, 0.f);
-                for (int t = 0; t < T; ++t) {
-                    const float2* __restrict__ coef = A.c_g + ((s * R + r) * T + t) * KTS;
-                    float2 h0 = make_float2(0.f, 0.f), h1 = make_float2(0.f, 0.f);
+            if constexpr (STAGED) {
+                // compute the whole unit into registers first: nothing here touches the slab, so this stretch overlaps the
+                // other waves' store-out of the previous unit
+                float2 hv[RGT * TT][2], qv[RGT][2];
 #pragma unroll
-                    for (int d = 0; d < NT; ++d) {
-                        const float2 c = coef[d];
-                        cfma(h0, c, make_float2(w[d].x, w[d].y));
-                        cfma(h1, c, make_float2(w[d].z, w[d].w));
+                for (int i = 0; i < RGT * TT; ++i) hv[i][0] = hv[i][1] = make_float2(0.f, 0.f);
+#pragma unroll
+                for (int d = 0; d < NT; ++d) {
+                    const float2 wa = w[d][0], wb = w_odd(d);
+                    const float2* __restrict__ cd = cs + (d * R + r0) * T;       // [rr][t] contiguous: one scalar load per tap
+#pragma unroll
+                    for (int i = 0; i < RGT * TT; ++i) {
+                        const float2 c = cd[i];
+                        cfma(hv[i][0], c, wa);
+                        cfma(hv[i][1], c, wb);
                     }
-                    if (Hb != nullptr) {
-                        if (v0) l_h[(rr * T + t) * nsc + k0] = h0;
-                        if (v1) l_h[(rr * T + t) * nsc + k1] = h1;
+                }
+#pragma unroll
+                for (int rr = 0; rr < RGT; ++rr) {
+                    const int r = r0 + rr;
+                    // sum_t H_t is accumulated from the per-tx rows, whether or not H is stored
+                    float2 hs0 = make_float2(0.f, 0.f), hs1 = make_float2(0.f, 0.f);
+#pragma unroll
+                    for (int t = 0; t < TT; ++t) {
+                        hs0.x += hv[rr * TT + t][0].x; hs0.y += hv[rr * TT + t][0].y;
+                        hs1.x += hv[rr * TT + t][1].x; hs1.y += hv[rr * TT + t][1].y;
                     }
-                    hs0.x += h0.x; hs0.y += h0.y; hs1.x += h1.x; hs1.y += h1.y;
+                    const float2 y0 = cmul(hs0, x0), y1 = cmul(hs1, x1);         // y = sum_t H x (:330-334)
+                    float2 n0v, n1v;
+                    if (nre != nullptr) {
+                        const unsigned row = (unsigned)(s * R + r) * (unsigned)nsc;
+                        n0v = make_float2((nre + row)[kc0], (nim + row)[kc0]);
+                        n1v = make_float2((nre + row)[kc1], (nim + row)[kc1]);
+                    } else {
+                        const u32x4 z = draw(A.key, STREAM_NOISE, (uint32_t)((s * R + r) * npair + pr));
+                        n0v = gauss_pair(z.x, z.y);
+                        n1v = gauss_pair(z.z, z.w);
+                    }
+                    qv[rr][0] = make_float2(fmaf(noise_std, n0v.x, y0.x), fmaf(noise_std, n0v.y, y0.y));
+                    qv[rr][1] = make_float2(fmaf(noise_std, n1v.x, y1.x), fmaf(noise_std, n1v.y, y1.y));
                 }
-                const float2 y0 = cmul(hs0, x0), y1 = cmul(hs1, x1);             // y = sum_t H x (:330-334)
-                float2 n0v, n1v;
-                if (nre != nullptr) {
-                    const unsigned row = (unsigned)(s * R + r) * (unsigned)nsc;
-                    n0v = make_float2((nre + row)[kc0], (nim + row)[kc0]);
-                    n1v = make_float2((nre + row)[kc1], (nim + row)[kc1]);
-                } else {
-                    const u32x4 z = draw(A.key, STREAM_NOISE, (uint32_t)(s * R + r) * npair + (uint32_t)tid);
-                    n0v = gauss_pair(z.x, z.y);
-                    n1v = gauss_pair(z.z, z.w);
+                STAMP_ADD(0);                                                    // W compute
+                if (!first_unit) __syncthreads();                                // previous unit's store-out has read the slab
+                first_unit = false;
+                STAMP_ADD(1);                                                    // W barrier B
+                if (act) {
+                    if (rg == 0 && txb != nullptr) {
+#pragma unroll
+                        for (int t = 0; t < TT; ++t) put(l_tx + t * nsc, x0, x1);
+                    }
+#pragma unroll
+                    for (int rr = 0; rr < RGT; ++rr) {
+                        const int r = r0 + rr;
+                        if (Hb != nullptr) {
+#pragma unroll
+                            for (int t = 0; t < TT; ++t) put(l_h + (rr * TT + t) * nsc, hv[rr * TT + t][0], hv[rr * TT + t][1]);
+                        }
+                        if (rxb != nullptr) put(l_rx + rr * nsc, qv[rr][0], qv[rr][1]);
+                        if (p0) hp[s0 * R + r] = pilot_divide(qv[rr][0], x0);    // (src/baseline_estimators.py:110)
+                        if (p1) hp[s1 * R + r] = pilot_divide(qv[rr][1], x1);
+                    }
                 }
-                const float2 q0 = make_float2(fmaf(noise_std, n0v.x, y0.x), fmaf(noise_std, n0v.y, y0.y));
-                const float2 q1 = make_float2(fmaf(noise_std, n1v.x, y1.x), fmaf(noise_std, n1v.y, y1.y));
-                if (rxb != nullptr) {
-                    if (v0) l_rx[rr * nsc + k0] = q0;
-                    if (v1) l_rx[rr * nsc + k1] = q1;
+            } else {
+                if (!first_unit) __syncthreads();                                // previous unit's store-out has read the slab
+                first_unit = false;
+                if (act && rg == 0 && txb != nullptr) {
+                    for (int t = 0; t < T; ++t) put(l_tx + t * nsc, x0, x1);
                 }
-                if (p0) hp[s0 * R + r] = pilot_divide(q0, x0);                   // (src/baseline_estimators.py:110)
-                if (p1) hp[s1 * R + r] = pilot_divide(q1, x1);
+                for (int rr = 0; rr < RG; ++rr) {
+                    const int r = r0 + rr;
+                    float2 hs0 = make_float2(0.f, 0.f), hs1 = make_float2(0.f, 0.f);
+                    for (int t = 0; t < T; ++t) {
+                        const float2* __restrict__ coef = cs + r * T + t;        // tap d at stride R*T
+                        float2 h0 = make_float2(0.f, 0.f), h1 = make_float2(0.f, 0.f);
+#pragma unroll
+                        for (int d = 0; d < NT; ++d) {
+                            const float2 c = coef[d * R * T];
+                            cfma(h0, c, w[d][0]);
+                            cfma(h1, c, w[d][NW - 1]);
+                        }
+                        if (act && Hb != nullptr) put(l_h + (rr * T + t) * nsc, h0, h1);
+                        hs0.x += h0.x; hs0.y += h0.y; hs1.x += h1.x; hs1.y += h1.y;
+                    }
+                    const float2 y0 = cmul(hs0, x0), y1 = cmul(hs1, x1);         // y = sum_t H x (:330-334)
+                    float2 n0v, n1v;
+                    if (nre != nullptr) {
+                        const unsigned row = (unsigned)(s * R + r) * (unsigned)nsc;
+                        n0v = make_float2((nre + row)[kc0], (nim + row)[kc0]);
+                        n1v = make_float2((nre + row)[kc1], (nim + row)[kc1]);
+                    } else {
+                        const u32x4 z = draw(A.key, STREAM_NOISE, (uint32_t)((s * R + r) * npair + pr));
+                        n0v = gauss_pair(z.x, z.y);
+                        n1v = gauss_pair(z.z, z.w);
+                    }
+                    const float2 q0 = make_float2(fmaf(noise_std, n0v.x, y0.x), fmaf(noise_std, n0v.y, y0.y));
+                    const float2 q1 = make_float2(fmaf(noise_std, n1v.x, y1.x), fmaf(noise_std, n1v.y, y1.y));
+                    if (act && rxb != nullptr) put(l_rx + rr * nsc, q0, q1);
+                    if (p0) hp[s0 * R + r] = pilot_divide(q0, x0);               // (src/baseline_estimators.py:110)
+                    if (p1) hp[s1 * R + r] = pilot_divide(q1, x1);
+                }
             }
+            STAMP_ADD(2);                                                        // W slab writes
             __syncthreads();                                                     // slab complete
-            int ph = wave;                                                       // rotate the stores of consecutive segments over the waves
-            if (rg == 0 && txb != nullptr) { const int n = seg_store(txb + e_tx, l_tx, T * nsc, ph, nwave, lane); ph = (ph + nwave - n % nwave) % nwave; }
-            if (Hb != nullptr) { const int n = seg_store(Hb + e_h, l_h, RG * T * nsc, ph, nwave, lane); ph = (ph + nwave - n % nwave) % nwave; }
-            if (rxb != nullptr) seg_store(rxb + e_rx, l_rx, RG * nsc, ph, nwave, lane);
+            STAMP_ADD(3);                                                        // W barrier A
+            if (storer) {
+                int ph = wave;                                                   // rotate the stores of consecutive segments over the waves
+                if (rg == 0 && txb != nullptr) { const int n = seg_store(txb + e_tx, l_tx, T * nsc, ph, nstw, lane); ph = (ph + nstw - n % nstw) % nstw; }
+                if (Hb != nullptr) { const int n = seg_store(Hb + e_h, l_h, RG * T * nsc, ph, nstw, lane); ph = (ph + nstw - n % nstw) % nstw; }
+                if (rxb != nullptr) seg_store(rxb + e_rx, l_rx, RG * nsc, ph, nstw, lane);
+            }
+            STAMP_ADD(4);                                                        // W store-out
         }
     }
+    float2* __restrict__ Lb = out.H_ls ? (float2*)out.H_ls + (size_t)b * S * R * T * nsc : nullptr;
+    float2* __restrict__ Mb = out.H_mmse ? (float2*)out.H_mmse + (size_t)b * S * R * T * nsc : nullptr;
     const bool want_metrics = out.metrics != nullptr;
     const bool want_est = (Lb != nullptr) || (Mb != nullptr) || want_metrics;
     __syncthreads();                                                             // hp complete; last store-out has read the slab
+    STAMP_ADD(5);                                                                // barrier after phase W
 
     // ---- pilot symbols in pilot order: regenerated from their own draws (identical arithmetic), linear 16-B stores ----
     if (out.pilot_symbols != nullptr) {
@@ -218,8 +344,8 @@ __device__ __forceinline__ void slab_body(const SlabArgs& A) {
                     u = usym[p];                                                 // first P draws are the pilot phases (:395)
                 } else {
                     const int g = pat.pilot_idx[p];
-                    const int s = g / nsc, k = g - s * nsc;
-                    const u32x4 z = draw(A.key, STREAM_SYM, (uint32_t)s * npair + ((uint32_t)k >> 1));
+                    const int sy = g / nsc, k = g - sy * nsc;
+                    const u32x4 z = draw(A.key, STREAM_SYM, (uint32_t)(sy * npair + (k >> 1)));
                     u = u01((k & 1) ? z.y : z.x);
                 }
                 xs[j] = cis_unit(__builtin_amdgcn_fractf(u));
@@ -257,6 +383,7 @@ __device__ __forceinline__ void slab_body(const SlabArgs& A) {
     float m_ls = 0.f, m_mm = 0.f;
     PlanRec c0n = plan[kc0], c1n = plan[kc1];
     first_unit = true;
+    STAMP_ADD(6);                                                                // pilot outputs + alpha
     for (int s = 0; s < S; ++s) {
         const PlanRec c0 = c0n, c1 = c1n;
         if (s + 1 < S) { c0n = plan[(s + 1) * nsc + kc0]; c1n = plan[(s + 1) * nsc + kc1]; }
@@ -265,48 +392,78 @@ __device__ __forceinline__ void slab_body(const SlabArgs& A) {
             const unsigned e_h = (unsigned)((s * R + r0) * T) * (unsigned)nsc;
             float2* __restrict__ l_l = slab + seg_l + ((par_h + e_h) & 1);
             float2* __restrict__ l_m = slab + seg_m + ((par_h + e_h) & 1);
-            if (!first_unit) __syncthreads();
-            first_unit = false;
-            for (int rr = 0; rr < RG; ++rr) {
-                const int r = r0 + rr;
-                const float2 e0 = interp(c0, hp, R, r), e1 = interp(c1, hp, R, r);
-                const float al = A.alpha[r];
-                const float2 f0 = make_float2(al * e0.x, al * e0.y), f1 = make_float2(al * e1.x, al * e1.y);
-                for (int t = 0; t < T; ++t) {
-                    const int row = (rr * T + t) * nsc;
-                    if (Lb != nullptr) { if (v0) l_l[row + k0] = e0; if (v1) l_l[row + k1] = e1; }
-                    if (Mb != nullptr) { if (v0) l_m[row + k0] = f0; if (v1) l_m[row + k1] = f1; }
-                }
-                if (want_metrics) {
-                    // sum_t |H_t - v|^2 = sum_t |H_t - Hbar|^2 + T |Hbar - v|^2 ; the first term is
-                    // estimate-independent and comes analytically from K1 (ST_SUM_VAR).
-                    const float2* __restrict__ coef = A.csum_g + (s * R + r) * KTS;
+            // the unit's estimates first (registers; reads hp only), then the slab hand-over
+            float2 ev[STAGED ? RGT : 1][2];
+            if constexpr (STAGED) {
+#pragma unroll
+                for (int rr = 0; rr < RGT; ++rr) { ev[rr][0] = interp(c0, hp, R, r0 + rr); ev[rr][1] = interp(c1, hp, R, r0 + rr); }
+            }
+            if (want_metrics) {
+                // sum_t |H_t - v|^2 = sum_t |H_t - Hbar|^2 + T |Hbar - v|^2 ; the first term is
+                // estimate-independent and comes analytically from K1 (ST_SUM_VAR).
+                for (int rr = 0; rr < RG; ++rr) {
+                    const int r = r0 + rr;
+                    const float al = A.alpha[r];
+                    float2 e0, e1;
+                    if constexpr (STAGED) { e0 = ev[rr][0]; e1 = ev[rr][1]; }
+                    else { e0 = interp(c0, hp, R, r); e1 = interp(c1, hp, R, r); }
+                    const float2* __restrict__ coef = A.csum_g + (size_t)s * KTS * R + r;      // tap d at stride R
                     float2 hb0 = make_float2(0.f, 0.f), hb1 = make_float2(0.f, 0.f);
 #pragma unroll
                     for (int d = 0; d < NT; ++d) {
-                        const float2 c = coef[d];
-                        cfma(hb0, c, make_float2(w[d].x, w[d].y));
-                        cfma(hb1, c, make_float2(w[d].z, w[d].w));
+                        const float2 c = coef[d * R];
+                        cfma(hb0, c, w[d][0]);
+                        cfma(hb1, c, w_odd(d));
                     }
-                    if (v0) {
-                        const float2 m = make_float2(hb0.x * invT, hb0.y * invT);
+                    if (act) {
+                        const float2 m = make_float2(hb0.x * invT, hb0.y * invT), f = make_float2(al * e0.x, al * e0.y);
                         m_ls += cabs2(make_float2(m.x - e0.x, m.y - e0.y));
-                        m_mm += cabs2(make_float2(m.x - f0.x, m.y - f0.y));
+                        m_mm += cabs2(make_float2(m.x - f.x, m.y - f.y));
                     }
                     if (v1) {
-                        const float2 m = make_float2(hb1.x * invT, hb1.y * invT);
+                        const float2 m = make_float2(hb1.x * invT, hb1.y * invT), f = make_float2(al * e1.x, al * e1.y);
                         m_ls += cabs2(make_float2(m.x - e1.x, m.y - e1.y));
-                        m_mm += cabs2(make_float2(m.x - f1.x, m.y - f1.y));
+                        m_mm += cabs2(make_float2(m.x - f.x, m.y - f.y));
                     }
                 }
             }
             if (Lb == nullptr && Mb == nullptr) continue;                        // metrics only: nothing to stream (uniform)
+            STAMP_ADD(7);                                                        // E compute (plan gather)
+            if (!first_unit) __syncthreads();
+            first_unit = false;
+            STAMP_ADD(8);                                                        // E barrier B
+            if (act) {
+                for (int rr = 0; rr < RG; ++rr) {
+                    const int r = r0 + rr;
+                    const float al = A.alpha[r];
+                    float2 e0, e1;
+                    if constexpr (STAGED) { e0 = ev[rr][0]; e1 = ev[rr][1]; }
+                    else { e0 = interp(c0, hp, R, r); e1 = interp(c1, hp, R, r); }
+                    const float2 f0 = make_float2(al * e0.x, al * e0.y), f1 = make_float2(al * e1.x, al * e1.y);
+                    for (int t = 0; t < T; ++t) {
+                        const int row = (rr * T + t) * nsc;
+                        if (Lb != nullptr) put(l_l + row, e0, e1);
+                        if (Mb != nullptr) put(l_m + row, f0, f1);
+                    }
+                }
+            }
+            STAMP_ADD(9);                                                        // E slab writes
             __syncthreads();
-            int ph = wave;
-            if (Lb != nullptr) { const int n = seg_store(Lb + e_h, l_l, RG * T * nsc, ph, nwave, lane); ph = (ph + nwave - n % nwave) % nwave; }
-            if (Mb != nullptr) seg_store(Mb + e_h, l_m, RG * T * nsc, ph, nwave, lane);
+            STAMP_ADD(10);                                                       // E barrier A
+            if (storer) {
+                int ph = wave;
+                if (Lb != nullptr) { const int n = seg_store(Lb + e_h, l_l, RG * T * nsc, ph, nstw, lane); ph = (ph + nstw - n % nstw) % nstw; }
+                if (Mb != nullptr) seg_store(Mb + e_h, l_m, RG * T * nsc, ph, nstw, lane);
+            }
+            STAMP_ADD(11);                                                       // E store-out
         }
     }
+#ifdef CHEST_STAMPS
+    if (g_stamp_buf != nullptr && lane == 0) {
+        unsigned long long* dst = g_stamp_buf + ((size_t)b * 16 + wave) * 16;
+        for (int i = 0; i < 12; ++i) dst[i] = st_sum[i];
+    }
+#endif
     if (want_metrics) {
         __syncthreads();
         m_ls = block_sum(m_ls, A.red);
@@ -324,7 +481,7 @@ __device__ __forceinline__ void slab_body(const SlabArgs& A) {
 }
 
 // MAXTHR: largest workgroup this instantiation is launched with (320 = 5 waves covers nsc <= 640, the 1024-FFT grids).
-template <int MAXTHR, int MINW>
+template <int MAXTHR, int MINW, int TT, int RR, int RGT, bool INJ>
 __global__ void __launch_bounds__(MAXTHR, MINW)
 frame_slab_kernel(const FrameParams* __restrict__ fpp, const chest_frame_desc* __restrict__ descs,
                   const PatternDev* __restrict__ patterns, int Pmax, uint64_t seed, uint64_t frame_offset,
@@ -334,6 +491,9 @@ frame_slab_kernel(const FrameParams* __restrict__ fpp, const chest_frame_desc* _
     const FrameParams& fp = *fpp;
     const int tid = threadIdx.x;
     int b = blockIdx.x;
+#ifdef CHEST_STAMPS
+    const unsigned long long st_rt0 = __builtin_amdgcn_s_memrealtime(), st_mt0 = __builtin_amdgcn_s_memtime();
+#endif
     {
         // Workgroups are dealt round-robin over the 8 XCDs (b % 8 labels the blocks that share one).  Give each XCD a
         // contiguous frame range: its L2 then holds one pattern group's tables and its writes are one sequential region.
@@ -403,31 +563,52 @@ frame_slab_kernel(const FrameParams* __restrict__ fpp, const chest_frame_desc* _
     A.key = RngKey{(uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)frame, (uint32_t)(frame >> 32)};
     A.b = b; A.RG = RG;
     switch (A.prof->ntaps) {                                     // workgroup-uniform dispatch on the profile
-        case 5: slab_body<5>(A); break;                          // EPA at 15.36 MHz
-        case 8: slab_body<8>(A); break;                          // EVA
-        default: slab_body<KT>(A); break;                        // ETU / anything else (taps padded with zeros)
+        case 5: slab_body<5, TT, RR, RGT, INJ>(A); break;             // EPA at 15.36 MHz
+        case 8: slab_body<8, TT, RR, RGT, INJ>(A); break;             // EVA
+        default: slab_body<KT, TT, RR, RGT, INJ>(A); break;           // ETU / anything else (taps padded with zeros)
     }
+#ifdef CHEST_STAMPS
+    if (g_stamp_buf != nullptr && (tid & 63) == 0) {
+        unsigned long long* dst = g_stamp_buf + ((size_t)b * 16 + (tid >> 6)) * 16;
+        unsigned hwid;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        dst[12] = st_rt0; dst[13] = __builtin_amdgcn_s_memrealtime(); dst[14] = __builtin_amdgcn_s_memtime() - st_mt0;
+        dst[15] = ((unsigned long long)xcc << 32) | hwid;
+    }
+#endif
 }
 
 size_t slab_lds_bytes(int nsc, int T, int R, int RG, int Pmax) {
     return ((((size_t)Pmax * R + 1) & ~(size_t)1) + (size_t)slab_elems(T, RG, nsc)) * sizeof(float2) + 40 * sizeof(float);
 }
 
-// Rx antennas per unit: the divisor of R that lets the most workgroups share a CU's 160 KiB of LDS (ties: the larger
-// group = longer contiguous bursts); ctx->tune_rx_group overrides (chest_tune, tools only).
+// Rx antennas per unit: the largest divisor of R whose slab still lets two workgroups share a CU's 160 KiB of LDS (long
+// contiguous bursts and few barriers matter more than a third or fourth resident workgroup: 2x2 frames measure 2.64 ms
+// with whole-symbol units against 3.21 ms with one rx antenna per unit); if none does, the largest that fits at all.
+// ctx->tune_rx_group overrides (chest_tune, tools only).
 static int choose_rx_group(const chest_ctx* ctx, int Pmax) {
     const FrameParams& fp = ctx->fp;
     if (ctx->tune_rx_group > 0 && fp.R % ctx->tune_rx_group == 0) return ctx->tune_rx_group;
-    int best = 1, best_wg = 0;
+    int best2 = 0, best1 = 1;
     for (int rg = 1; rg <= fp.R; ++rg) {
         if (fp.R % rg) continue;
         const size_t lds = slab_lds_bytes(fp.nsc, fp.T, fp.R, rg, Pmax);
-        if (lds > 160 * 1024) continue;
-        int wg = (int)((160 * 1024) / lds);
-        if (wg > 4) wg = 4;                                      // register file: 4 waves per SIMD at <= 128 VGPRs
-        if (wg >= best_wg) { best_wg = wg; best = rg; }
+        if (lds <= 80 * 1024) best2 = rg;
+        if (lds <= 160 * 1024) best1 = rg;
     }
-    return best;
+    return best2 ? best2 : best1;
+}
+
+template <int MAXTHR, int MINW, int TT, int RR, int RGT, bool INJ>
+static int launch_one(chest_ctx* ctx, int which, hipStream_t st, dim3 grid, dim3 block, size_t lds, const chest_frame_desc* descs, int Pmax,
+                      uint64_t seed, uint64_t frame_offset, const chest_injected& inj, const chest_frame_outputs& out,
+                      const float* workspace, int RG) {
+    CHEST_LDS_OPT_IN(ctx, which, (frame_slab_kernel<MAXTHR, MINW, TT, RR, RGT, INJ>), lds);
+    hipLaunchKernelGGL((frame_slab_kernel<MAXTHR, MINW, TT, RR, RGT, INJ>), grid, block, lds, st, ctx->d_fp, descs, ctx->d_patterns, Pmax,
+                       seed, frame_offset, inj, out, workspace, RG, ctx->d_status);
+    return CHEST_OK;
 }
 
 int launch_k2_slab(chest_ctx* ctx, hipStream_t st, int32_t B, const chest_frame_desc* descs, int Pmax, uint64_t seed,
@@ -439,20 +620,31 @@ int launch_k2_slab(chest_ctx* ctx, hipStream_t st, int32_t B, const chest_frame_
     const size_t lds = slab_lds_bytes(fp.nsc, fp.T, fp.R, RG, Pmax);
     if (lds > 160 * 1024) { set_error("frame kernel needs %zu B of LDS (> 160 KiB): too many antennas, subcarriers or pilots", lds); return CHEST_EINVAL; }
     const dim3 grid((unsigned)B), block((unsigned)nwave * 64);
-    if (nwave <= 5) {
-        CHEST_LDS_OPT_IN(ctx, LDS_FRAME, (frame_slab_kernel<320, 4>), lds);
-        hipLaunchKernelGGL((frame_slab_kernel<320, 4>), grid, block, lds, st, ctx->d_fp, descs, ctx->d_patterns, Pmax, seed, frame_offset,
-                           inj, out, workspace, RG, ctx->d_status);
-    } else if (nwave <= 10) {
-        CHEST_LDS_OPT_IN(ctx, LDS_FRAME_640, (frame_slab_kernel<640, 3>), lds);
-        hipLaunchKernelGGL((frame_slab_kernel<640, 3>), grid, block, lds, st, ctx->d_fp, descs, ctx->d_patterns, Pmax, seed, frame_offset,
-                           inj, out, workspace, RG, ctx->d_status);
-    } else {
-        CHEST_LDS_OPT_IN(ctx, LDS_FRAME_1024, (frame_slab_kernel<1024, 4>), lds);
-        hipLaunchKernelGGL((frame_slab_kernel<1024, 4>), grid, block, lds, st, ctx->d_fp, descs, ctx->d_patterns, Pmax, seed, frame_offset,
-                           inj, out, workspace, RG, ctx->d_status);
+    const int T = fp.T, R = fp.R;
+#define CHEST_SLAB_ARGS st, grid, block, lds, descs, Pmax, seed, frame_offset, inj, out, workspace, RG
+    const bool injected = inj.u_sym || inj.u_angle || inj.n_re;         // parity / replay mode: the generic instantiations
+    if (nwave <= 5) {                      // the 1024-FFT grids (nsc <= 640): specialised antenna counts on the device-RNG path
+        if (!injected) {
+            if (fp.half & 1) return launch_one<320, 4, 0, 0, 0, true>(ctx, LDS_FRAME_GEN, CHEST_SLAB_ARGS);   // a pair straddles DC
+            // 2x2: 96 VGPRs (five waves per SIMD) so that THREE 5-wave workgroups are resident per CU -- at 128 VGPRs only two
+            // are placed although 15 waves would fit; 2.00 against 2.33 ms per 10 000 frames (chest_tune "frame_min_waves" = 4
+            // selects the 128-VGPR instantiation for A/B)
+            if (T == 2 && R == 2 && RG == 2 && ctx->tune_min_waves == 4) return launch_one<320, 4, 2, 2, 2, false>(ctx, LDS_FRAME_W5, CHEST_SLAB_ARGS);
+            if (T == 2 && R == 2 && RG == 2) return launch_one<320, 5, 2, 2, 2, false>(ctx, LDS_FRAME, CHEST_SLAB_ARGS);
+            if (T == 4 && R == 4 && RG == 1) return launch_one<320, 4, 4, 4, 1, false>(ctx, LDS_FRAME_44, CHEST_SLAB_ARGS);
+            if (T == 1 && R == 1 && RG == 1) return launch_one<320, 5, 1, 1, 1, false>(ctx, LDS_FRAME_11, CHEST_SLAB_ARGS);
+        }
+        return launch_one<320, 4, 0, 0, 0, true>(ctx, LDS_FRAME_GEN, CHEST_SLAB_ARGS);
     }
-    return CHEST_OK;
+    if (nwave <= 10) return launch_one<640, 3, 0, 0, 0, true>(ctx, LDS_FRAME_640, CHEST_SLAB_ARGS);
+    return launch_one<1024, 4, 0, 0, 0, true>(ctx, LDS_FRAME_1024, CHEST_SLAB_ARGS);
+#undef CHEST_SLAB_ARGS
 }
 
 }  // namespace chest
+
+#ifdef CHEST_STAMPS
+extern "C" int chest_debug_set_stamp_buffer(void* dev_ptr) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(chest::g_stamp_buf), &dev_ptr, sizeof(void*)) == hipSuccess ? 0 : -2;
+}
+#endif

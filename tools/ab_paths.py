@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """In-process A/B of the frame kernel's write paths on ONE set of output buffers (first allocation, no placement probing):
-slab path (default) with each admissible rx-group size against the legacy row-store path.  Prints the library's own
+slab path with each admissible rx-group size and register budget (the legacy row-store kernel it replaced is gone).  Prints the library's own
 HIP-event kernel times (median of --reps launches, interleaved round-robin so that clock / thermal drift hits all alike).
 
     python tools/ab_paths.py [--workload cfg2|cfg3|cfg1] [--frames N] [--reps 9] [--sets 2]
@@ -24,7 +24,6 @@ def main():
     ap.add_argument("--frames", type=int, default=0)
     ap.add_argument("--reps", type=int, default=9)
     ap.add_argument("--sets", type=int, default=2, help="independently allocated output sets (placement spread)")
-    ap.add_argument("--no-legacy", action="store_true")
     args = ap.parse_args()
     import torch
     E = importlib.import_module(PKG + ".engine")
@@ -42,9 +41,9 @@ def main():
     d_dev = torch.from_numpy(descs.view(np.uint8).copy()).to(eng.device)
     names = ["tx", "rx", "H", "H_ls", "H_mmse", "pilot_symbols", "pilot_mask"]
     sets = [eng.run_frames(d_dev, seed=1, outputs=names) for _ in range(args.sets)]
-    variants = [("slab rg=%d" % rg, {"frame_legacy_rows": 0, "frame_rx_group": rg}) for rg in range(1, R + 1) if R % rg == 0]
-    if not args.no_legacy:
-        variants.append(("legacy rows", {"frame_legacy_rows": 1, "frame_rx_group": 0}))
+    variants = [("slab rg=%d" % rg, {"frame_rx_group": rg, "frame_min_waves": 0}) for rg in range(1, R + 1) if R % rg == 0 and rg <= 2]
+    if T == 2:
+        variants.append(("slab rg=2 w4", {"frame_rx_group": 2, "frame_min_waves": 4}))
     bytes_frame = 8 * G * (T + R + 3 * R * T) + G + 8 * P
     times = {(v, i): [] for v, _ in variants for i in range(args.sets)}
     for rep in range(args.reps + 1):
