@@ -224,8 +224,16 @@ def test_bench_algorithmic_bytes_match_the_survey_formula():
     assert bench.algorithmic_bytes_per_frame(14, 599, 4, 4, 838, 2) == 3772018
     assert bench.algorithmic_bytes_per_frame(14, 599, 1, 1, 838, 2) == 350530
     assert bench.algorithmic_bytes_per_frame(14, 599, 2, 2, 838, 2) + 4 * 838 == 1091850       # SURVEY's figure for config 2
-    assert set(bench.WORKLOADS) >= {"cfg2_2x2_eva_ls_mmse", "cfg3_4x4_etu_mmse", "cfg1_siso_epa_ls"}
-    assert bench.WORKLOADS["cfg2_2x2_eva_ls_mmse"][-1] == 10000 and bench.HBM_PEAK_GBS == 8000.0
+    # config 4 (dataset schema: float32 mask, 32-B metric record, no per-pilot bytes) and config 5 (one estimate tensor, N = 2048)
+    assert bench.algorithmic_bytes_per_frame(14, 599, 2, 2, 0, 2, mask_bytes=4, extra=32) == 1106952 + 32      # SURVEY: 1 106 976 with 24 B of meta
+    assert bench.algorithmic_bytes_per_frame(14, 1199, 4, 4, 1678, 1) + 4 * 1678 == 5408442                    # SURVEY's figure for config 5
+    assert set(bench.WORKLOADS) >= {"cfg2_2x2_eva_ls_mmse", "cfg3_4x4_etu_mmse", "cfg1_siso_epa_ls", "cfg4_dataset_mixed",
+                                    "cfg5_4x4_2048_fullcov"}
+    assert bench.WORKLOADS["cfg2_2x2_eva_ls_mmse"]["frames"] == 10000 and bench.HBM_PEAK_GBS == 8000.0
+    # the harness-defined covariance of config 5 is Hermitian with T on the diagonal (sum of tap powers 1, J0(0) = 1)
+    pil = np.sort(np.random.RandomState(0).permutation(14 * 71)[:40])
+    C = bench.fullcov_covariance(1024, 72, 72, 2, "ETU", 300.0, pil)
+    assert np.allclose(C, C.conj().T) and np.allclose(np.diag(C).real, 2.0)
 
 
 def test_utils_host_helpers_follow_the_reference():
