@@ -183,6 +183,7 @@ void chest_destroy(chest_ctx* ctx) {
     (void)hipDeviceSynchronize();
     for (auto& p : ctx->patterns)
         if (p.block) (void)hipFree(p.block);
+    for (auto& pl : ctx->pools) { if (pl.block) (void)hipFree(pl.block); if (pl.d_meta) (void)hipFree(pl.d_meta); }
     if (ctx->d_patterns) (void)hipFree(ctx->d_patterns);
     if (ctx->d_status) (void)hipFree(ctx->d_status);
     if (ctx->d_twiddle) (void)hipFree(ctx->d_twiddle);
@@ -316,7 +317,7 @@ int chest_pattern_set_triangulation(chest_ctx* ctx, int32_t slot, const int32_t*
 }
 
 int chest_pattern_get_plan(chest_ctx* ctx, int32_t slot, uint16_t* plan_idx, float* plan_w) {
-    if (!ctx || slot < 0 || (size_t)slot >= ctx->patterns.size() || ctx->patterns[slot].block == nullptr) {
+    if (!ctx || slot < 0 || (size_t)slot >= ctx->patterns.size() || ctx->patterns[slot].dev.slot == nullptr) {
         set_error("pattern slot %d is not set", slot);
         return CHEST_ESTATE;
     }
@@ -326,6 +327,7 @@ int chest_pattern_get_plan(chest_ctx* ctx, int32_t slot, uint16_t* plan_idx, flo
     struct Rec { float w0, w1; uint32_t i01, i2v; };
     std::vector<Rec> recs(G);
     CHEST_GUARD(ctx);
+    CHEST_HIP(hipDeviceSynchronize());
     CHEST_HIP(hipMemcpy(recs.data(), ctx->patterns[slot].dev.plan, (size_t)G * sizeof(Rec), hipMemcpyDeviceToHost));
     for (int g = 0; g < G; ++g) {
         const Rec& r = recs[g];
@@ -339,7 +341,7 @@ int chest_pattern_get_plan(chest_ctx* ctx, int32_t slot, uint16_t* plan_idx, flo
 }
 
 int chest_pattern_num_pilots(chest_ctx* ctx, int32_t slot) {
-    if (!ctx || slot < 0 || (size_t)slot >= ctx->patterns.size() || ctx->patterns[slot].block == nullptr) {
+    if (!ctx || slot < 0 || (size_t)slot >= ctx->patterns.size() || ctx->patterns[slot].dev.slot == nullptr) {
         set_error("pattern slot %d is not set", slot);
         return CHEST_ESTATE;
     }

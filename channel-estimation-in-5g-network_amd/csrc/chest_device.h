@@ -13,7 +13,9 @@ namespace chest {
 //   STREAM_OSC   index = ((path*T + tx)*R + rx)*20 + n      word x -> angle uniform, y -> phase uniform
 //   STREAM_SYM   index = s*npair + (k>>1)                   word (k&1) -> symbol phase uniform of RE (s,k)
 //   STREAM_NOISE index = (s*R + r)*npair + (k>>1)           words (x,y) -> k even, (z,w) -> k odd   (npair = ceil(nsc/2))
-enum : uint32_t { STREAM_OSC = 1, STREAM_SYM = 2, STREAM_NOISE = 3 };
+//   STREAM_PATTERN (frame words = pattern id) index = g>>2, word (g&3) -> selection key of resource element g: the P
+//                smallest keys are the pilots of a device-drawn pattern (chest_patterns_build)
+enum : uint32_t { STREAM_OSC = 1, STREAM_SYM = 2, STREAM_NOISE = 3, STREAM_PATTERN = 4 };
 
 struct u32x4 { uint32_t x, y, z, w; };
 

@@ -50,8 +50,17 @@ struct PatternDev {
 };
 
 struct PatternHost {
-    void* block = nullptr;         // one hipMalloc per pattern
+    void* block = nullptr;         // one hipMalloc per pattern (nullptr for patterns that live in a pool)
     PatternDev dev{};
+};
+
+// Storage of a batch of device-built patterns (chest_patterns_build): one allocation for `count` equally sized blocks
+// slot u16[G] | pilot_idx i32[Pcap] | plan PlanRec[G], reused in place when the same slot range is rebuilt.
+struct PatternPool {
+    int32_t first_slot = 0, count = 0, Pcap = 0;
+    size_t stride = 0, o_pil = 0, o_plan = 0;
+    void* block = nullptr;
+    void* d_meta = nullptr;        // per-pattern pilot counts and pattern ids on the device
 };
 
 }  // namespace chest
@@ -63,6 +72,7 @@ struct chest_ctx {
     int32_t delay_samples[CHEST_NUM_PROFILES][CHEST_MAX_PATHS];
     int32_t num_paths[CHEST_NUM_PROFILES];
     std::vector<chest::PatternHost> patterns;
+    std::vector<chest::PatternPool> pools;
     std::vector<float2> gram_host;
     chest::PatternDev* d_patterns = nullptr;   // device mirror, capacity pattern_cap
     int32_t pattern_cap = 0;

@@ -1,0 +1,592 @@
+// Batched on-device construction of pilot patterns and their interpolation plans: one workgroup per pattern, no host work.
+//
+//   reference path replaced, once per frame in the reference (src/channel_simulator.py:390-391, src/baseline_estimators.py:65-79):
+//     PilotPattern.__init__            src/channel_simulator.py:209-236   shuffle, take P, sort  -> a uniformly random P-subset
+//     griddata(method='linear')        scipy: Qhull Delaunay of the pilot positions, then per resource element the containing
+//                                      simplex and its barycentric weights, 0 outside the convex hull
+//     griddata(method='nearest')       scipy: cKDTree nearest pilot
+//
+// Per pattern (tools/delaunay_model.py is the CPU model of steps 3-4, used by the tests):
+//   1. pilot selection: every resource element gets a Philox key (seed, pattern id, element); the P smallest keys (ties by
+//      element index) are the pilots -- the order statistics of a random permutation, i.e. the same distribution as the
+//      reference's shuffle-and-take-P.  (Or the caller supplies the sorted pilot list.)
+//   2. slot table (draw slot of every resource element) by binary search in the sorted pilot list.
+//   3. initial triangulation.  Pilots are lattice points on S parallel rows: each strip between two consecutive occupied
+//      rows is triangulated by merging the two sorted rows; the step number of every triangle and of its three neighbours
+//      follows from rank arithmetic (two binary searches per triangle, all triangles in parallel).  The pockets between the
+//      left / right end chains and the convex hull are filled by one thread (a monotone-chain scan over <= S points a side).
+//   4. Lawson flips with the EXACT integer in-circle test (|det| < 2^50 in int64) in rounds of independent flips until every
+//      interior edge is locally Delaunay.  The result is a valid Delaunay triangulation; it equals Qhull's wherever the
+//      triangulation is unique, i.e. everywhere except inside co-circular lattice polygons, where any choice is Delaunay
+//      and the reference's is an artefact of Qhull's facet merging (parity definition: SURVEY 7, hard part 1, option ii).
+//   5. plan: every resource element walks (visibility walk, exact integer orientation tests; acyclic on Delaunay
+//      triangulations) from its predecessor's triangle to the one containing it and stores the three pilot ordinals and two
+//      barycentric weights; elements outside the hull get weight 0 (griddata's fill_value).
+//   'nearest': per occupied row a binary search for the closest pilot columns, minimum squared distance, ties to the
+//   smaller pilot ordinal (cKDTree's tie choice depends on its internal split order and is not reproduced).
+#include "chest_device.h"
+#include "chest_internal.h"
+
+namespace chest {
+
+constexpr int PB_THREADS = 256;
+constexpr uint32_t TNONE = 0xFFFFu;
+constexpr int PB_MAX_ROWS = CHEST_MAX_SYMBOLS;
+
+struct PatBuildArgs {
+    PatternDev* table;            // device pattern table; entries first_slot + j are written by the kernel
+    unsigned char* pool;          // count blocks of `stride` bytes: slot u16[G] | pilot_idx i32[Pcap] | plan PlanRec[G]
+    size_t stride, o_pil, o_plan;
+    const int32_t* num_pilots;    // [count]
+    const int32_t* given_idx;     // [count][idx_stride] sorted flat indices, or nullptr: draw them
+    const uint64_t* pattern_ids;  // [count]
+    uint64_t seed;
+    int32_t idx_stride, first_slot, S, nsc, method, Pcap;
+    int32_t* simp_out;            // optional [count][2*Pcap][3]
+    int32_t* nsimp_out;           // optional [count]
+    int32_t* status;
+};
+
+struct PatLds {
+    uint32_t* pts;                // [P] (row << 16 | col), ascending
+    uint16_t* tv[3];              // triangle vertices (pilot ordinals), counter-clockwise in (row, col)
+    uint16_t* tn[3];              // tn[i][t]: triangle across the edge opposite vertex i, TNONE on the hull
+    uint32_t* claim;              // [NT]
+    uint16_t* partner;            // [NT] TNONE = not flipped this round
+    int* misc;                    // small scalars / per-row tables
+};
+
+__device__ __forceinline__ int px_of(uint32_t v) { return (int)(v >> 16); }
+__device__ __forceinline__ int py_of(uint32_t v) { return (int)(v & 0xFFFFu); }
+__device__ __forceinline__ int orient2(uint32_t a, uint32_t b, uint32_t c) {
+    return (px_of(b) - px_of(a)) * (py_of(c) - py_of(a)) - (py_of(b) - py_of(a)) * (px_of(c) - px_of(a));
+}
+// > 0 iff d lies strictly inside the circumcircle of the counter-clockwise triangle (a, b, c)
+__device__ __forceinline__ long long incircle(uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
+    const long long adx = px_of(a) - px_of(d), ady = py_of(a) - py_of(d), bdx = px_of(b) - px_of(d), bdy = py_of(b) - py_of(d),
+                    cdx = px_of(c) - px_of(d), cdy = py_of(c) - py_of(d);
+    return (adx * adx + ady * ady) * (bdx * cdy - cdx * bdy) - (bdx * bdx + bdy * bdy) * (adx * cdy - cdx * ady) +
+           (cdx * cdx + cdy * cdy) * (adx * bdy - bdx * ady);
+}
+// number of entries of the ascending array a[0..n) that are < key / <= key
+__device__ __forceinline__ int count_less(const uint32_t* a, int n, uint32_t key) {
+    int lo = 0, hi = n;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (a[mid] < key) lo = mid + 1; else hi = mid; }
+    return lo;
+}
+__device__ __forceinline__ int count_leq(const uint32_t* a, int n, uint32_t key) {
+    int lo = 0, hi = n;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (a[mid] <= key) lo = mid + 1; else hi = mid; }
+    return lo;
+}
+
+// exclusive scan of one value per thread over the workgroup; `scr` = PB_THREADS + 1 ints of LDS; returns (exclusive prefix, total)
+__device__ __forceinline__ int2 block_exscan(int v, int* scr) {
+    const int tid = threadIdx.x;
+    scr[tid] = v;
+    __syncthreads();
+    for (int off = 1; off < PB_THREADS; off <<= 1) {
+        const int t = tid >= off ? scr[tid - off] : 0;
+        __syncthreads();
+        scr[tid] += t;
+        __syncthreads();
+    }
+    const int incl = scr[tid], tot = scr[PB_THREADS - 1];
+    __syncthreads();
+    return make_int2(incl - v, tot);
+}
+
+size_t pattern_build_lds_bytes(int G, int Pcap) {
+    const size_t tri = (size_t)4 * Pcap + (size_t)2 * Pcap * (6 * 2 + 4 + 2);        // pts | tv, tn | claim | partner
+    const size_t keys = (size_t)4 * G;
+    return (tri > keys ? tri : keys) + (size_t)(PB_THREADS + 8 + 4 * (PB_MAX_ROWS + 2)) * sizeof(int) + 64;
+}
+
+__global__ void __launch_bounds__(PB_THREADS)
+pattern_build_kernel(const PatBuildArgs A) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    const int tid = threadIdx.x, j = blockIdx.x;
+    const int S = A.S, nsc = A.nsc, G = S * nsc;
+    const int P = A.num_pilots[j];
+    unsigned char* base = A.pool + (size_t)j * A.stride;
+    uint16_t* __restrict__ slotp = (uint16_t*)base;
+    int32_t* __restrict__ pil = (int32_t*)(base + A.o_pil);
+    PlanRec* __restrict__ plan = (PlanRec*)(base + A.o_plan);
+    if (tid == 0) {
+        PatternDev pd;
+        pd.slot = slotp; pd.plan = A.method >= 0 ? (const void*)plan : nullptr; pd.pilot_idx = pil; pd.P = P; pd.pad = 0;
+        A.table[A.first_slot + j] = pd;
+        if (A.nsimp_out) A.nsimp_out[j] = 0;
+    }
+    if (P < 1 || P > A.Pcap || P > G) { if (tid == 0) atomicExch(A.status, 1); return; }
+
+    // ---- LDS carve-up: the key array of step 1 shares its space with the triangle arrays of steps 3-5 ----------------
+    const int NT = 2 * A.Pcap;
+    int* misc = (int*)lds_raw;                                   // [PB_THREADS + 8 + 4 * (rows + 2)]
+    int* scan = misc;                                            // PB_THREADS + 1
+    int* cnt_s = misc + PB_THREADS + 1;                          // a few scalars
+    int* rowstart = misc + PB_THREADS + 8;                       // [rows + 1] first pilot of every row
+    int* occ = rowstart + PB_MAX_ROWS + 2;                       // occupied rows
+    int* toff = occ + PB_MAX_ROWS + 2;                           // first triangle of every strip
+    unsigned char* big = (unsigned char*)(toff + PB_MAX_ROWS + 2);
+    big = (unsigned char*)(((uintptr_t)big + 15) & ~(uintptr_t)15);
+    uint32_t* keys = (uint32_t*)big;
+    uint32_t* pts = (uint32_t*)big;
+    uint16_t* tv0 = (uint16_t*)(pts + A.Pcap); uint16_t* tv1 = tv0 + NT; uint16_t* tv2 = tv1 + NT;
+    uint16_t* tn0 = tv2 + NT; uint16_t* tn1 = tn0 + NT; uint16_t* tn2 = tn1 + NT;
+    uint32_t* claim = (uint32_t*)(tn2 + NT);
+    uint16_t* partner = (uint16_t*)(claim + NT);
+    auto TV = [&](int c) -> uint16_t* { return c == 0 ? tv0 : (c == 1 ? tv1 : tv2); };
+    auto TN = [&](int c) -> uint16_t* { return c == 0 ? tn0 : (c == 1 ? tn1 : tn2); };
+
+    // ================= 1. pilots =================================================================================
+    const int per = (G + PB_THREADS - 1) / PB_THREADS;           // contiguous element block of this thread
+    const int g_lo = min(G, tid * per), g_hi = min(G, g_lo + per);
+    if (A.given_idx != nullptr) {
+        for (int i = tid; i < P; i += PB_THREADS) pil[i] = A.given_idx[(size_t)j * A.idx_stride + i];
+    } else {
+        const uint64_t pid = A.pattern_ids[j];
+        const RngKey key{(uint32_t)A.seed, (uint32_t)(A.seed >> 32), (uint32_t)pid, (uint32_t)(pid >> 32)};
+        for (int q = tid; q < (G + 3) / 4; q += PB_THREADS) {                 // one Philox call keys four elements
+            const u32x4 w = draw(key, STREAM_PATTERN, (uint32_t)q);
+            const int g = 4 * q;
+            keys[g] = w.x;
+            if (g + 1 < G) keys[g + 1] = w.y;
+            if (g + 2 < G) keys[g + 2] = w.z;
+            if (g + 3 < G) keys[g + 3] = w.w;
+        }
+        __syncthreads();
+        // smallest threshold tau with #{key <= tau} >= P (bisection on the 32 bits; counts through one LDS counter)
+        uint32_t lo = 0, hi = 0xFFFFFFFFu;
+        while (lo < hi) {
+            const uint32_t mid = lo + ((hi - lo) >> 1);
+            if (tid == 0) cnt_s[0] = 0;
+            __syncthreads();
+            int c = 0;
+            for (int g = g_lo; g < g_hi; ++g) c += keys[g] <= mid ? 1 : 0;
+            c = (int)wave_sum((float)c);                                      // <= 64 * per < 2^24: exact in float
+            if ((tid & 63) == 0) atomicAdd(&cnt_s[0], c);
+            __syncthreads();
+            const int tot = cnt_s[0];
+            __syncthreads();
+            if (tot >= P) hi = mid; else lo = mid + 1;
+        }
+        const uint32_t tau = lo;
+        int nl = 0, ne = 0;
+        for (int g = g_lo; g < g_hi; ++g) { nl += keys[g] < tau ? 1 : 0; ne += keys[g] == tau ? 1 : 0; }
+        const int2 sl = block_exscan(nl, scan);
+        const int2 se = block_exscan(ne, scan);
+        const int need_eq = P - sl.y;                                         // keys equal to tau to take, in element order
+        int pos = sl.x + min(se.x, need_eq), eq_seen = se.x;
+        for (int g = g_lo; g < g_hi; ++g) {
+            const uint32_t kq = keys[g];
+            bool take = kq < tau;
+            if (kq == tau) { take = eq_seen < need_eq; ++eq_seen; }
+            if (take) pil[pos++] = g;
+        }
+        __threadfence_block();
+    }
+    __syncthreads();                                             // pil complete (global, read back by this workgroup only)
+    for (int i = tid; i < P; i += PB_THREADS) {
+        const int g = pil[i];
+        const int s = g / nsc;
+        pts[i] = ((uint32_t)s << 16) | (uint32_t)(g - s * nsc);
+    }
+    __syncthreads();
+
+    // ================= 2. slot table ==============================================================================
+    {
+        int g = g_lo;
+        int s = g / nsc, k = g - s * nsc;
+        for (; g < g_hi; ++g) {
+            const uint32_t key = ((uint32_t)s << 16) | (uint32_t)k;
+            const int pos = count_less(pts, P, key);
+            slotp[g] = (uint16_t)((pos < P && pts[pos] == key) ? pos : P + (g - pos));
+            if (++k == nsc) { k = 0; ++s; }
+        }
+    }
+    if (A.method < 0) return;                                    // simulation-only pattern: no plan
+
+    // per-row tables
+    for (int r = tid; r <= S; r += PB_THREADS) rowstart[r] = count_less(pts, P, (uint32_t)r << 16);
+    __syncthreads();
+    if (tid == 0) {
+        int m = 0, t = 0;
+        for (int r = 0; r < S; ++r) if (rowstart[r + 1] > rowstart[r]) occ[m++] = r;
+        for (int q = 0; q + 1 < m; ++q) {
+            toff[q] = t;
+            t += (rowstart[occ[q] + 1] - rowstart[occ[q]]) + (rowstart[occ[q + 1] + 1] - rowstart[occ[q + 1]]) - 2;
+        }
+        toff[m > 0 ? m - 1 : 0] = t;
+        cnt_s[1] = m; cnt_s[2] = t;                              // occupied rows, strip triangles
+    }
+    __syncthreads();
+    const int m = cnt_s[1];
+
+    if (A.method == 1) {
+        // ================= 'nearest' plan ========================================================================
+        int g = g_lo;
+        int s = g / nsc, k = g - s * nsc;
+        for (; g < g_hi; ++g) {
+            int best = 0x7fffffff, bi = 0;
+            for (int q = 0; q < m; ++q) {
+                const int r = occ[q], a = rowstart[r], n = rowstart[r + 1] - a;
+                const int c = count_less(pts + a, n, ((uint32_t)r << 16) | (uint32_t)k);      // first column >= k
+                const int dr = (r - s) * (r - s);
+                if (c > 0) { const int dc = k - py_of(pts[a + c - 1]); const int d2 = dr + dc * dc; if (d2 < best) { best = d2; bi = a + c - 1; } }
+                if (c < n) { const int dc = py_of(pts[a + c]) - k; const int d2 = dr + dc * dc; if (d2 < best) { best = d2; bi = a + c; } }
+            }
+            plan[g] = PlanRec{1.0f, 0.0f, (uint32_t)bi | ((uint32_t)bi << 16), (uint32_t)bi | (1u << 16)};
+            if (++k == nsc) { k = 0; ++s; }
+        }
+        return;
+    }
+
+    // ================= 3. initial triangulation ====================================================================
+    const int nstrip = cnt_s[2];
+    // every pilot emits the triangle that advances from it to its right-hand neighbour in its row: once as a point of the
+    // upper row of the strip below it (A-step) and once as a point of the lower row of the strip above it (B-step)
+    for (int p = tid; p < P; p += PB_THREADS) {
+        const int r = px_of(pts[p]);
+        int q = 0;
+        while (occ[q] != r) ++q;                                 // occupied-row index (<= S steps)
+        const int a0 = rowstart[r], na = rowstart[r + 1] - a0, i = p - a0;
+        if (i + 1 >= na) continue;                               // last point of its row: no step starts here
+        const uint32_t nextcol = (uint32_t)py_of(pts[p + 1]);
+        if (q + 1 < m) {
+            // A-step of strip q: triangle (a_i, b_j, a_{i+1}), j = B-steps taken before = #{j' >= 1 : colB[j'] < col(a_{i+1})}
+            const int rb = occ[q + 1], b0 = rowstart[rb], nb = rowstart[rb + 1] - b0;
+            const uint32_t kb = ((uint32_t)rb << 16) | nextcol;
+            const int jb = count_less(pts + b0, nb, kb) - ((pts[b0] < kb) ? 1 : 0);
+            const int k = i + jb, t = toff[q] + k, nq = na + nb - 2;
+            tv0[t] = (uint16_t)p; tv1[t] = (uint16_t)(b0 + jb); tv2[t] = (uint16_t)(p + 1);
+            tn0[t] = (uint16_t)(k + 1 < nq ? t + 1 : TNONE);     // rung after the step
+            tn2[t] = (uint16_t)(k > 0 ? t - 1 : TNONE);          // rung before the step
+            // across the row edge: the B-step of the strip above that advances over the same edge
+            uint32_t up = TNONE;
+            if (q > 0) {
+                const int ru = occ[q - 1], u0 = rowstart[ru], nu = rowstart[ru + 1] - u0;
+                const uint32_t ku = ((uint32_t)ru << 16) | nextcol;
+                const int ia = count_leq(pts + u0, nu, ku) - ((pts[u0] <= ku) ? 1 : 0);     // A-steps before it (ties: upper row first)
+                up = (uint32_t)(toff[q - 1] + i + ia);
+            }
+            tn1[t] = (uint16_t)up;
+        }
+        if (q > 0) {
+            // B-step of strip q-1: triangle (b_j, b_{j+1}, a_i) with j = i here, i_A = #{i' >= 1 : colA[i'] <= col(b_{j+1})}
+            const int ru = occ[q - 1], u0 = rowstart[ru], nu = rowstart[ru + 1] - u0;
+            const uint32_t ku = ((uint32_t)ru << 16) | nextcol;
+            const int ia = count_leq(pts + u0, nu, ku) - ((pts[u0] <= ku) ? 1 : 0);
+            const int k = i + ia, t = toff[q - 1] + k, nq = nu + na - 2;
+            tv0[t] = (uint16_t)p; tv1[t] = (uint16_t)(p + 1); tv2[t] = (uint16_t)(u0 + ia);
+            tn0[t] = (uint16_t)(k + 1 < nq ? t + 1 : TNONE);     // rung after
+            tn1[t] = (uint16_t)(k > 0 ? t - 1 : TNONE);          // rung before
+            uint32_t dn = TNONE;
+            if (q + 1 < m) {
+                const int rb = occ[q + 1], b0 = rowstart[rb], nb = rowstart[rb + 1] - b0;
+                const uint32_t kb = ((uint32_t)rb << 16) | nextcol;
+                const int jb = count_less(pts + b0, nb, kb) - ((pts[b0] < kb) ? 1 : 0);
+                dn = (uint32_t)(toff[q] + i + jb);
+            }
+            tn2[t] = (uint16_t)dn;
+        }
+    }
+    __syncthreads();
+    // pockets between the end chains and the convex hull (one thread; <= 2 (m - 2) triangles)
+    if (tid == 0) {
+        int nt = nstrip;
+        const int first_pocket = nt;
+        int stack[PB_MAX_ROWS + 1];
+        for (int side = 0; side < 2; ++side) {
+            int sp = 0;
+            for (int q = 0; q < m; ++q) {
+                const int r = occ[q];
+                const int p = side == 0 ? rowstart[r] : rowstart[r + 1] - 1;
+                while (sp >= 2) {
+                    const int a = stack[sp - 2], b = stack[sp - 1];
+                    const int o = orient2(pts[a], pts[b], pts[p]);
+                    // b lies in a pocket if it is on the inner side of a -> p (left chain: o < 0, right chain: o > 0)
+                    if (side == 0 ? o < 0 : o > 0) {
+                        // counter-clockwise: (a, p, b) on the left chain, (a, b, p) on the right one
+                        tv0[nt] = (uint16_t)a; tv1[nt] = (uint16_t)(side == 0 ? p : b); tv2[nt] = (uint16_t)(side == 0 ? b : p);
+                        tn0[nt] = tn1[nt] = tn2[nt] = (uint16_t)TNONE;
+                        ++nt; --sp;
+                    } else break;
+                }
+                stack[sp++] = p;
+            }
+        }
+        // adjacency of the pocket triangles: against each other, and against the end triangles of the strips
+        for (int t = first_pocket; t < nt; ++t) {
+            for (int c = 0; c < 3; ++c) {
+                const uint32_t x = TV((c + 1) % 3)[t], y = TV((c + 2) % 3)[t];
+                uint32_t found = TNONE;
+                int fslot = 0;
+                for (int u = first_pocket; u < nt && found == TNONE; ++u) {
+                    if (u == t) continue;
+                    for (int d = 0; d < 3; ++d)
+                        if (TV((d + 1) % 3)[u] == y && TV((d + 2) % 3)[u] == x) { found = (uint32_t)u; fslot = d; }
+                }
+                if (found == TNONE) {
+                    // a chain edge between consecutive occupied rows: the first / last triangle of that strip
+                    for (int q = 0; q + 1 < m && found == TNONE; ++q) {
+                        const int nq = toff[q + 1] - toff[q];
+                        if (nq <= 0) continue;
+                        const int cand[2] = {toff[q], toff[q] + nq - 1};
+                        for (int e = 0; e < 2 && found == TNONE; ++e)
+                            for (int d = 0; d < 3; ++d)
+                                if (TV((d + 1) % 3)[cand[e]] == y && TV((d + 2) % 3)[cand[e]] == x && TN(d)[cand[e]] == TNONE) {
+                                    found = (uint32_t)cand[e]; fslot = d;
+                                }
+                    }
+                }
+                if (found != TNONE) { TN(c)[t] = (uint16_t)found; TN(fslot)[found] = (uint16_t)t; }
+            }
+        }
+        cnt_s[2] = nt;
+    }
+    __syncthreads();
+    const int ntri = cnt_s[2];
+
+    // ================= 4. Lawson flips ==============================================================================
+    for (int round = 0; round < 4 * NT + 64; ++round) {
+        for (int t = tid; t < ntri; t += PB_THREADS) { claim[t] = 0xFFFFFFFFu; partner[t] = (uint16_t)TNONE; }
+        if (tid == 0) cnt_s[3] = 0;
+        __syncthreads();
+        // phase 0: every interior edge (t < u) that fails the in-circle test claims both of its triangles
+        for (int t = tid; t < ntri; t += PB_THREADS) {
+            const uint32_t v[3] = {tv0[t], tv1[t], tv2[t]};
+            const uint32_t n[3] = {tn0[t], tn1[t], tn2[t]};
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const uint32_t u = n[i];
+                if (u == TNONE || u < (uint32_t)t) continue;
+                const uint32_t b = v[(i + 1) % 3], c = v[(i + 2) % 3];
+                const uint32_t u0 = tv0[u], u1 = tv1[u], u2 = tv2[u];
+                const uint32_t d = (u0 != b && u0 != c) ? u0 : ((u1 != b && u1 != c) ? u1 : u2);
+                if (incircle(pts[v[i]], pts[b], pts[c], pts[d]) > 0) {
+                    const uint32_t key = (uint32_t)t * 4u + (uint32_t)i;
+                    atomicMin(&claim[t], key);
+                    atomicMin(&claim[u], key);
+                    cnt_s[3] = 1;
+                }
+            }
+        }
+        __syncthreads();
+        if (cnt_s[3] == 0) break;
+        // phase 1: winners rewrite their two triangles; outer neighbours keep their OLD ids for now
+        for (int t = tid; t < ntri; t += PB_THREADS) {
+            const uint32_t key = claim[t];
+            if ((key >> 2) != (uint32_t)t) continue;             // the winning edge of t belongs to another (smaller) triangle, or none
+            const int i = (int)(key & 3u);
+            const uint32_t u = TN(i)[t];
+            if (claim[u] != key) continue;
+            const uint32_t a = TV(i)[t], b = TV((i + 1) % 3)[t], c = TV((i + 2) % 3)[t];
+            const uint32_t n_ab = TN((i + 2) % 3)[t], n_ca = TN((i + 1) % 3)[t];
+            const uint32_t u0 = tv0[u], u1 = tv1[u];
+            const int jd = (u0 != b && u0 != c) ? 0 : ((u1 != b && u1 != c) ? 1 : 2);
+            const uint32_t d = TV(jd)[u];
+            // u = (d, c, b) rotated so that u[jd] = d: the edge opposite c is (b, d), the edge opposite b is (d, c)
+            const uint32_t n_db = TN((jd + 1) % 3)[u], n_cd = TN((jd + 2) % 3)[u];
+            tv0[t] = (uint16_t)a; tv1[t] = (uint16_t)b; tv2[t] = (uint16_t)d;
+            tn0[t] = (uint16_t)n_db; tn1[t] = (uint16_t)u; tn2[t] = (uint16_t)n_ab;
+            tv0[u] = (uint16_t)a; tv1[u] = (uint16_t)d; tv2[u] = (uint16_t)c;
+            tn0[u] = (uint16_t)n_cd; tn1[u] = (uint16_t)n_ca; tn2[u] = (uint16_t)t;
+            partner[t] = (uint16_t)u; partner[u] = (uint16_t)t;
+        }
+        __syncthreads();
+        // phase 2: every new triangle resolves its outer neighbours (the old neighbour, or its partner if that one flipped
+        // too) and writes the back-pointer of neighbours that did not flip
+        for (int X = tid; X < ntri; X += PB_THREADS) {
+            const uint32_t pX = partner[X];
+            if (pX == TNONE) continue;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                uint32_t Y = TN(k)[X];
+                if (Y == TNONE || Y == pX) continue;
+                const uint32_t x = TV((k + 1) % 3)[X], y = TV((k + 2) % 3)[X];
+                const uint32_t pY = partner[Y];
+                if (pY != TNONE) {
+                    const uint32_t y0 = tv0[Y], y1 = tv1[Y], y2 = tv2[Y];
+                    const bool has = (y0 == x || y1 == x || y2 == x) && (y0 == y || y1 == y || y2 == y);
+                    if (!has) Y = pY;
+                    TN(k)[X] = (uint16_t)Y;
+                } else {
+                    const uint32_t y0 = tv0[Y], y1 = tv1[Y];
+                    const int k2 = (y0 != x && y0 != y) ? 0 : ((y1 != x && y1 != y) ? 1 : 2);
+                    TN(k2)[Y] = (uint16_t)X;
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    if (A.simp_out != nullptr) {
+        int32_t* so = A.simp_out + (size_t)j * 2 * A.Pcap * 3;
+        for (int t = tid; t < ntri; t += PB_THREADS) { so[3 * t] = tv0[t]; so[3 * t + 1] = tv1[t]; so[3 * t + 2] = tv2[t]; }
+        if (tid == 0 && A.nsimp_out) A.nsimp_out[j] = ntri;
+    }
+
+    // ================= 5. plan: walk to the containing triangle =====================================================
+    {
+        int g = g_lo;
+        int s = g / nsc, k = g - s * nsc;
+        int t = ntri > 0 ? (int)(((long long)g_lo * ntri) / (G > 0 ? G : 1)) : 0;     // strips are laid out in element order
+        for (; g < g_hi; ++g) {
+            PlanRec rec{0.f, 0.f, 0u, 0u};
+            if (ntri > 0) {
+                const uint32_t q = ((uint32_t)s << 16) | (uint32_t)k;
+                bool found = false, outside = false;
+                for (int step = 0; step < ntri + 8 && !found && !outside; ++step) {
+                    const uint32_t i0 = tv0[t], i1 = tv1[t], i2 = tv2[t];
+                    const uint32_t a = pts[i0], b = pts[i1], c = pts[i2];
+                    const int o0 = orient2(b, c, q), o1 = orient2(c, a, q), o2 = orient2(a, b, q);
+                    uint32_t nx = TNONE;
+                    bool cross = false;
+                    if (o0 < 0) { nx = tn0[t]; cross = true; }
+                    else if (o1 < 0) { nx = tn1[t]; cross = true; }
+                    else if (o2 < 0) { nx = tn2[t]; cross = true; }
+                    if (!cross) {
+                        const float den = (float)(o0 + o1 + o2);
+                        rec.w0 = (float)o0 / den; rec.w1 = (float)o1 / den;
+                        rec.i01 = i0 | (i1 << 16); rec.i2v = i2 | (1u << 16);
+                        found = true;
+                    } else if (nx == TNONE) outside = true;      // the way out crosses a hull edge: outside the convex hull
+                    else t = (int)nx;
+                }
+                if (!found && !outside) {
+                    // not reached on a Delaunay triangulation (the visibility walk is acyclic); exhaustive scan as a safety net
+                    for (int u = 0; u < ntri; ++u) {
+                        const uint32_t i0 = tv0[u], i1 = tv1[u], i2 = tv2[u];
+                        const int o0 = orient2(pts[i1], pts[i2], q), o1 = orient2(pts[i2], pts[i0], q), o2 = orient2(pts[i0], pts[i1], q);
+                        if ((o0 | o1 | o2) >= 0) {
+                            const float den = (float)(o0 + o1 + o2);
+                            rec.w0 = (float)o0 / den; rec.w1 = (float)o1 / den;
+                            rec.i01 = i0 | (i1 << 16); rec.i2v = i2 | (1u << 16);
+                            t = u;
+                            break;
+                        }
+                    }
+                }
+            }
+            plan[g] = rec;
+            if (++k == nsc) { k = 0; ++s; }
+        }
+    }
+}
+
+}  // namespace chest
+
+using namespace chest;
+
+extern "C" int chest_patterns_build(chest_ctx* ctx, void* stream, int32_t first_slot, int32_t count, const int32_t* num_pilots,
+                                    const int32_t* pilot_idx, int32_t idx_stride, uint64_t seed, const uint64_t* pattern_ids,
+                                    int32_t method, int32_t* simplices_out, int32_t* num_simplices_out) {
+    if (!ctx || first_slot < 0 || count < 0 || first_slot + (int64_t)count > (1 << 24) || (count > 0 && !num_pilots)) {
+        set_error("chest_patterns_build: bad argument");
+        return CHEST_EINVAL;
+    }
+    if (count == 0) return CHEST_OK;
+    if (method < -1 || method > 1) { set_error("chest_patterns_build: method must be -1 (no plan), 0 ('linear') or 1 ('nearest')"); return CHEST_EINVAL; }
+    if (pilot_idx == nullptr && pattern_ids == nullptr) { set_error("chest_patterns_build: give pilot_idx or pattern_ids"); return CHEST_EINVAL; }
+    CHEST_GUARD(ctx);
+    hipStream_t st = (hipStream_t)stream;
+    const int G = ctx->fp.G;
+    int Pmax = 1;
+    for (int i = 0; i < count; ++i) {
+        if (num_pilots[i] < 1 || num_pilots[i] > G || (pilot_idx && num_pilots[i] > idx_stride)) {
+            set_error("chest_patterns_build: num_pilots[%d] = %d out of range", i, num_pilots[i]);
+            return CHEST_EINVAL;
+        }
+        Pmax = num_pilots[i] > Pmax ? num_pilots[i] : Pmax;
+    }
+    if (Pmax >= 0xFFFF / 2) { set_error("chest_patterns_build: at most 32766 pilots per pattern"); return CHEST_EINVAL; }
+    const size_t lds = pattern_build_lds_bytes(G, Pmax);
+    if (lds > 160 * 1024) {
+        set_error("chest_patterns_build: %d pilots need %zu B of LDS (> 160 KiB); use chest_pattern_set_triangulation for such patterns", Pmax, lds);
+        return CHEST_EINVAL;
+    }
+    auto up = [](size_t v, size_t a) { return (v + a - 1) / a * a; };
+    // pool reuse: the slot range is served by one pool whose blocks are large enough -> build in place (stream ordered)
+    PatternPool* pool = nullptr;
+    for (auto& pl : ctx->pools)
+        if (pl.first_slot == first_slot && pl.count >= count && pl.Pcap >= Pmax) pool = &pl;
+    if (pool == nullptr) {
+        CHEST_HIP(hipDeviceSynchronize());
+        // release whatever owned these slots before
+        for (auto it = ctx->pools.begin(); it != ctx->pools.end();) {
+            const bool overlap = it->first_slot < first_slot + count && first_slot < it->first_slot + it->count;
+            if (overlap) {
+                for (int s = it->first_slot; s < it->first_slot + it->count && s < (int)ctx->patterns.size(); ++s) ctx->patterns[s] = PatternHost{};
+                (void)hipFree(it->block); (void)hipFree(it->d_meta);
+                it = ctx->pools.erase(it);
+            } else ++it;
+        }
+        if ((size_t)(first_slot + count) > ctx->patterns.size()) ctx->patterns.resize(first_slot + count);
+        for (int s = first_slot; s < first_slot + count; ++s)
+            if (ctx->patterns[s].block) { (void)hipFree(ctx->patterns[s].block); ctx->patterns[s] = PatternHost{}; }
+        PatternPool pl{};
+        pl.first_slot = first_slot; pl.count = count; pl.Pcap = Pmax;
+        pl.o_pil = up((size_t)G * 2, 16);
+        pl.o_plan = up(pl.o_pil + (size_t)Pmax * 4, 256);
+        pl.stride = up(pl.o_plan + (size_t)G * sizeof(PlanRec), 256);
+        if (hipMalloc((void**)&pl.block, pl.stride * (size_t)count) != hipSuccess) { set_error("chest_patterns_build: out of device memory (%zu B)", pl.stride * (size_t)count); return CHEST_ENOMEM; }
+        if (hipMalloc((void**)&pl.d_meta, (size_t)count * (sizeof(int32_t) + sizeof(uint64_t))) != hipSuccess) { (void)hipFree(pl.block); set_error("out of device memory"); return CHEST_ENOMEM; }
+        ctx->pools.push_back(pl);
+        pool = &ctx->pools.back();
+        // make sure the device table covers the range
+        const int last = first_slot + count - 1;
+        if (last >= ctx->pattern_cap) {
+            int cap = ctx->pattern_cap ? ctx->pattern_cap : 16;
+            while (cap <= last) cap *= 2;
+            PatternDev* nd = nullptr;
+            CHEST_HIP(hipMalloc((void**)&nd, (size_t)cap * sizeof(PatternDev)));
+            CHEST_HIP(hipMemset(nd, 0, (size_t)cap * sizeof(PatternDev)));
+            if (ctx->d_patterns && ctx->pattern_cap) CHEST_HIP(hipMemcpy(nd, ctx->d_patterns, (size_t)ctx->pattern_cap * sizeof(PatternDev), hipMemcpyDeviceToDevice));
+            CHEST_HIP(hipDeviceSynchronize());
+            if (ctx->d_patterns) CHEST_HIP(hipFree(ctx->d_patterns));
+            ctx->d_patterns = nd;
+            ctx->pattern_cap = cap;
+        }
+    }
+    // per-pattern pilot counts and ids to the device (small; ordered on the launch stream)
+    int32_t* d_np = (int32_t*)pool->d_meta;
+    uint64_t* d_ids = (uint64_t*)((unsigned char*)pool->d_meta + up((size_t)pool->count * sizeof(int32_t), 8));
+    CHEST_HIP(hipMemcpyAsync(d_np, num_pilots, (size_t)count * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    if (pattern_ids) CHEST_HIP(hipMemcpyAsync(d_ids, pattern_ids, (size_t)count * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+    PatBuildArgs a{};
+    a.table = ctx->d_patterns; a.pool = (unsigned char*)pool->block; a.stride = pool->stride; a.o_pil = pool->o_pil; a.o_plan = pool->o_plan;
+    a.num_pilots = d_np; a.given_idx = pilot_idx; a.pattern_ids = d_ids; a.seed = seed; a.idx_stride = idx_stride;
+    a.first_slot = first_slot; a.S = ctx->fp.S; a.nsc = ctx->fp.nsc; a.method = method; a.Pcap = pool->Pcap;
+    a.simp_out = simplices_out; a.nsimp_out = num_simplices_out; a.status = ctx->d_status;
+    if (simplices_out && pool->Pcap != Pmax) { set_error("chest_patterns_build: simplices_out needs a fresh slot range (row stride is 2*Pmax*3)"); return CHEST_EINVAL; }
+    const size_t lds_run = pattern_build_lds_bytes(G, pool->Pcap);
+    CHEST_LDS_OPT_IN(ctx, LDS_DELAUNAY, pattern_build_kernel, lds_run);
+    const int sp = prof_open(ctx, st, CHEST_K_PLAN);
+    hipLaunchKernelGGL(pattern_build_kernel, dim3((unsigned)count), dim3(PB_THREADS), lds_run, st, a);
+    prof_close(ctx, st, sp);
+    CHEST_HIP(hipGetLastError());
+    // host mirror of the table entries
+    for (int i = 0; i < count; ++i) {
+        PatternHost& ph = ctx->patterns[first_slot + i];
+        unsigned char* base = (unsigned char*)pool->block + (size_t)i * pool->stride;
+        ph.block = nullptr;                                      // owned by the pool
+        ph.dev.slot = (const uint16_t*)base;
+        ph.dev.plan = method >= 0 ? (const void*)(base + pool->o_plan) : nullptr;
+        ph.dev.pilot_idx = (const int32_t*)(base + pool->o_pil);
+        ph.dev.P = num_pilots[i];
+    }
+    return CHEST_OK;
+}
+
+/* pilot list of a slot back to the host (sorted flat indices); synchronises on the device */
+extern "C" int chest_pattern_get_pilots(chest_ctx* ctx, int32_t slot, int32_t* pilot_idx_out) {
+    if (!ctx || !pilot_idx_out || slot < 0 || (size_t)slot >= ctx->patterns.size() || ctx->patterns[slot].dev.slot == nullptr) {
+        set_error("pattern slot %d is not set", slot);
+        return CHEST_ESTATE;
+    }
+    CHEST_GUARD(ctx);
+    CHEST_HIP(hipDeviceSynchronize());
+    CHEST_HIP(hipMemcpy(pilot_idx_out, ctx->patterns[slot].dev.pilot_idx, (size_t)ctx->patterns[slot].dev.P * sizeof(int32_t), hipMemcpyDeviceToHost));
+    return CHEST_OK;
+}

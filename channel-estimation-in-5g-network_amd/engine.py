@@ -191,6 +191,47 @@ class Engine:
     def num_pilots(self, slot: int) -> int:
         return self._slot_P[int(slot)]
 
+    METHOD_CODES = {None: -1, "none": -1, "linear": 0, "nearest": 1}
+
+    def build_patterns(self, first_slot, num_pilots, pilot_idx=None, seed=0, pattern_ids=None, method="linear",
+                       return_simplices=False):
+        """Build ``len(num_pilots)`` patterns and their plans ON THE DEVICE in slots ``first_slot ...`` (one launch, one
+        workgroup per pattern: pilot selection, slot table, Delaunay triangulation / nearest search, plan).  Either
+        ``pattern_ids`` (uint64 per pattern: the pilots are drawn on the device from (seed, id)) or ``pilot_idx`` (device or
+        host int32 [count, stride] rows of sorted flat indices).  Rebuilding the same slot range reuses its storage in
+        place, ordered on the current stream.  Returns the slot numbers (and, on request, (simplices, counts) tensors)."""
+        npil = np.ascontiguousarray(num_pilots, dtype=np.int32).reshape(-1)
+        count = len(npil)
+        ids = None if pattern_ids is None else np.ascontiguousarray(pattern_ids, dtype=np.uint64).reshape(-1)
+        if ids is not None and len(ids) != count:
+            raise ValueError("pattern_ids and num_pilots differ in length")
+        idx_t, stride = None, 0
+        if pilot_idx is not None:
+            idx_t = self._dev(pilot_idx, torch.int32)
+            if idx_t.dim() != 2 or idx_t.shape[0] != count:
+                raise ValueError("pilot_idx must be [count, stride]")
+            stride = idx_t.shape[1]
+        simp = cnt = None
+        if return_simplices:
+            simp = torch.zeros(count, 2 * int(npil.max()), 3, dtype=torch.int32, device=self.device)
+            cnt = torch.zeros(count, dtype=torch.int32, device=self.device)
+        N.check(N.lib().chest_patterns_build(self._h, self._stream(), int(first_slot), count, npil.ctypes.data,
+                                             None if idx_t is None else idx_t.data_ptr(), int(stride), int(seed) & (2**64 - 1),
+                                             None if ids is None else ids.ctypes.data, self.METHOD_CODES[method],
+                                             None if simp is None else simp.data_ptr(), None if cnt is None else cnt.data_ptr()),
+                "chest_patterns_build")
+        for i in range(count):
+            self._slot_P[int(first_slot) + i] = int(npil[i])
+        self._next_slot = max(self._next_slot, int(first_slot) + count)
+        slots = np.arange(first_slot, first_slot + count, dtype=np.int32)
+        return (slots, simp, cnt) if return_simplices else slots
+
+    def get_pilots(self, slot: int) -> np.ndarray:
+        """Sorted flat pilot indices of a slot (host copy; synchronises)."""
+        out = np.empty(self.num_pilots(slot), dtype=np.int32)
+        N.check(N.lib().chest_pattern_get_pilots(self._h, int(slot), out.ctypes.data), "chest_pattern_get_pilots")
+        return out
+
     def check_status(self):
         st = C.c_int32()
         N.check(N.lib().chest_get_status(self._h, C.byref(st)), "chest_get_status")

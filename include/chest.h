@@ -150,6 +150,26 @@ int chest_pattern_set(chest_ctx* ctx, int32_t slot, const int32_t* pilot_idx, in
  * simplex's three ordinals and barycentric weights; weights 0 outside the hull. */
 int chest_pattern_set_triangulation(chest_ctx* ctx, int32_t slot, const int32_t* pilot_idx, int32_t num_pilots,
                                     const int32_t* simplices, int32_t num_simplices);
+/* Batched ON-DEVICE construction of `count` pilot patterns and their interpolation plans in slots first_slot ...
+ * first_slot + count - 1, one workgroup per pattern and no host work per pattern -- what the reference does once per frame
+ * (PilotPattern(...) at src/channel_simulator.py:390-391, griddata's triangulation at src/baseline_estimators.py:65-79):
+ *   pilots   pilot_idx == NULL: pattern i is the num_pilots[i] resource elements with the smallest Philox keys of
+ *            (seed, pattern_ids[i]) -- the order statistics of a random permutation, i.e. PilotPattern's shuffle-take-sort
+ *            distribution (:224-229); else DEVICE int32 [count][idx_stride] rows of sorted flat indices.
+ *   method   0 'linear': Delaunay triangulation of the lattice pilots on the device (exact integer predicates; identical to
+ *              Qhull's wherever the triangulation is unique, an arbitrary valid choice inside co-circular polygons), then
+ *              per resource element the containing triangle and its barycentric weights, 0 outside the hull;
+ *            1 'nearest': nearest pilot by squared lattice distance, ties to the smaller pilot ordinal;
+ *           -1 no plan (simulation only).
+ *   num_pilots, pattern_ids: HOST arrays [count].  simplices_out (optional, DEVICE int32 [count][2*Pmax][3], Pmax =
+ *   max num_pilots) / num_simplices_out (DEVICE int32 [count]) receive the triangulations.
+ * The slots' storage is one pool allocation; rebuilding the same slot range with no larger patterns reuses it in place,
+ * ordered on `stream` (no synchronisation, no allocation), which is how a per-frame-pattern producer loop uses it. */
+int chest_patterns_build(chest_ctx* ctx, void* stream, int32_t first_slot, int32_t count, const int32_t* num_pilots,
+                         const int32_t* pilot_idx, int32_t idx_stride, uint64_t seed, const uint64_t* pattern_ids,
+                         int32_t method, int32_t* simplices_out, int32_t* num_simplices_out);
+/* Sorted flat pilot indices of a slot back to the HOST (int32 [P]); synchronises. */
+int chest_pattern_get_pilots(chest_ctx* ctx, int32_t slot, int32_t* pilot_idx_out);
 /* Read a slot's plan back in chest_pattern_set's layout: HOST plan_idx uint16[3][G], plan_w float[3][G]. */
 int chest_pattern_get_plan(chest_ctx* ctx, int32_t slot, uint16_t* plan_idx, float* plan_w);
 int chest_pattern_num_pilots(chest_ctx* ctx, int32_t slot);

@@ -80,3 +80,17 @@ def native_frame_draws(seed, frame, pilot_indices, num_symbols, num_sc, num_tx, 
     n_im = np.stack([im0, im1], axis=-1).reshape(S, R, npair * 2)[:, :, :nsc]
     return dict(pilot_indices=np.asarray(pilot_indices), u_pilot=u_flat[mask], u_data=u_flat[~mask], u_angle=u_angle,
                 u_phase=u_phase, n_re=n_re, n_im=n_im)
+
+
+STREAM_PATTERN = 4
+
+
+def native_pilot_pattern(seed, pattern_id, grid, num_pilots):
+    """Pilot set of a device-drawn pattern (csrc/pattern_kernels.hip step 1): resource element g gets the key
+    word (g & 3) of draw(seed, frame = pattern_id, STREAM_PATTERN, index = g >> 2); the num_pilots smallest keys, ties by
+    element index, are the pilots.  Returns the sorted flat indices -- a uniformly random subset, the distribution of
+    PilotPattern's shuffle / take / sort (src/channel_simulator.py:224-229)."""
+    w = draw(seed, pattern_id, STREAM_PATTERN, np.arange((grid + 3) // 4))
+    keys = np.stack(w, axis=1).reshape(-1)[:grid].astype(np.uint64)
+    order = np.lexsort((np.arange(grid), keys))            # by key, ties by element index
+    return np.sort(order[:num_pilots]).astype(np.int32)
