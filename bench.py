@@ -270,37 +270,58 @@ def run(args):
     workers = args.plan_workers or min(16, os.cpu_count() or 1)
 
     # ---- inputs resident in HBM before the timed region: patterns, plans (descriptors too, except for the dataset) -------
+    # --patterns device (default): pilots drawn (Philox), triangulated (Delaunay) and turned into plans ON THE DEVICE, one
+    # launch for all patterns (Engine.build_patterns); --patterns host: legacy np.random shuffle + Qhull on the host cores.
     t_plan = time.perf_counter()
+    device_patterns = args.patterns == "device"
+    per_step_patterns = False
     if kind == "dataset":
-        # one pattern per (density, group of `group` consecutive GLOBAL frames) over the frame range this job will touch
+        # one pattern per (density, group of `group` consecutive GLOBAL frames) over the frame range this job will touch;
+        # group == 1: a new pattern for EVERY frame, built inside the timed step from (seed, global frame index)
         dens_list = list(w["densities"])
+        npil_of_density = np.asarray([int(G * d) for d in dens_list], dtype=np.int32)
+        per_step_patterns = device_patterns and group == 1
         first_group, last_group = 0, (total_steps * world * F - 1) // group
-        pils, keys = [], []
-        for di, d in enumerate(dens_list):
-            for gidx in range(first_group, last_group + 1):
+        keys = [(di, gidx) for di in range(len(dens_list)) for gidx in range(first_group, last_group + 1)] if not per_step_patterns else []
+        if per_step_patterns:
+            pils, slots = [], []
+            eng.build_patterns(0, np.full(F, npil_of_density.max(), np.int32), seed=seed, pattern_ids=np.arange(F, dtype=np.uint64), method="linear")   # reserves the slot range
+        elif device_patterns:
+            ids = np.asarray([gidx * len(dens_list) + di for di, gidx in keys], dtype=np.uint64)
+            slots = eng.build_patterns(0, npil_of_density[[di for di, _ in keys]], seed=seed, pattern_ids=ids, method="linear")
+            pils = [None] * len(keys)
+        else:
+            pils = []
+            for di, gidx in keys:
                 perm = np.arange(G)
                 np.random.RandomState((seed * 1000003 + gidx * 101 + di) % (2 ** 32)).shuffle(perm)   # PilotPattern's shuffle
-                pils.append(np.sort(perm[: int(G * d)])); keys.append((di, gidx))
-    elif kind == "fullcov":
-        perm = np.arange(G)
-        np.random.RandomState(2024).shuffle(perm)
-        pils = [np.sort(perm[: int(G * w["dens"])])]
+                pils.append(np.sort(perm[: int(G * dens_list[di])]))
     else:
-        npat = (F + group - 1) // group
-        pils = []
-        for gidx in range(npat):
-            perm = np.arange(G)
-            np.random.RandomState(2024 + gidx).shuffle(perm)
-            pils.append(np.sort(perm[: int(G * w["dens"])]))
-    eng.max_cached_patterns = max(eng.max_cached_patterns, len(pils) + 8)
-    if len(pils) >= 4 * workers:            # Qhull Delaunay on the host (~2 ms per pattern per core); point location on the GPU;
-        slots = [eng.pattern_slot(pil, "linear", plan=tri)            # uploads overlap the pool's remaining triangulations
-                 for pil, tri in zip(pils, IP.triangulations_iter(pils, S, nsc, workers))]
+        npat = 1 if kind == "fullcov" else (F + group - 1) // group
+        if device_patterns:
+            slots = eng.build_patterns(0, np.full(npat, int(G * w["dens"]), np.int32), seed=2024, pattern_ids=np.arange(npat, dtype=np.uint64), method="linear")
+            pils = [eng.get_pilots(int(slots[0]))] if kind == "fullcov" else [None] * npat
+        else:
+            pils = []
+            for gidx in range(npat):
+                perm = np.arange(G)
+                np.random.RandomState(2024 + gidx).shuffle(perm)
+                pils.append(np.sort(perm[: int(G * w["dens"])]))
+    if not device_patterns:
+        eng.max_cached_patterns = max(eng.max_cached_patterns, len(pils) + 8)
+        if len(pils) >= 4 * workers:        # Qhull Delaunay on the host (~2 ms per pattern per core); point location on the GPU;
+            slots = [eng.pattern_slot(pil, "linear", plan=tri)            # uploads overlap the pool's remaining triangulations
+                     for pil, tri in zip(pils, IP.triangulations_iter(pils, S, nsc, workers))]
+        else:
+            workers = 1
+            slots = [eng.pattern_slot(pil, "linear") for pil in pils]
     else:
-        workers = 1
-        slots = [eng.pattern_slot(pil, "linear") for pil in pils]
+        workers = 0
+    torch.cuda.synchronize()
+    eng.check_status()
     t_plan = time.perf_counter() - t_plan
-    P = max(len(p) for p in pils)
+    P = int(G * max(w["densities"])) if kind == "dataset" else int(G * w["dens"])
+    npatterns = F if per_step_patterns else len(slots)
 
     names = ["tx", "rx", "H", "H_ls", "H_mmse", "pilot_symbols", "pilot_mask"]
     extra = {}
@@ -309,6 +330,7 @@ def run(args):
         slot_of = np.full((len(dens_list), last_group + 1), -1, dtype=np.int32)
         for (di, gidx), sl in zip(keys, slots):
             slot_of[di, gidx] = sl
+        frame_slots = np.arange(F, dtype=np.int32)
         types_code = np.asarray([E.channel_code(c) for c in w["types"]], dtype=np.int32)
         dop = np.asarray(w["dopplers"], np.float32); snrs = np.asarray(w["snrs"], np.float32)
 
@@ -317,9 +339,15 @@ def run(args):
             ci, di, si, pi = SH.frame_choices(seed, idx, (len(types_code), len(dop), len(snrs), len(dens_list)))
             d = np.empty(F, dtype=E.DESC_DTYPE)
             d["channel_type"] = types_code[ci]; d["doppler_hz"] = dop[di]; d["snr_db"] = snrs[si]
-            d["pattern_slot"] = slot_of[pi, idx // group]
+            d["pattern_slot"] = frame_slots if per_step_patterns else slot_of[pi, idx // group]
+            return d, (npil_of_density[pi], idx.astype(np.uint64))
+
+        def dataset_step(off):
+            d, (npil, ids) = descs_for(off)
+            if per_step_patterns:           # every frame draws its own pilot pattern: selection + Delaunay + plan, in place
+                eng.build_patterns(0, npil, seed=seed, pattern_ids=ids, method="linear")
             return d
-        d_first = descs_for(rank * F)
+        d_first = dataset_step(rank * F)
     else:
         if kind == "fullcov":
             names = ["tx", "rx", "H", "pilot_symbols", "pilot_mask", "h_ls_pilots"]
@@ -358,7 +386,7 @@ def run(args):
     def step(i):
         off = (i * world + rank) * F
         if kind == "dataset":
-            eng.run_frames(descs_for(off), seed=seed, frame_offset=off, outputs=names, out=out, check=False)
+            eng.run_frames(dataset_step(off), seed=seed, frame_offset=off, outputs=names, out=out, check=False)
         elif kind == "fullcov":
             eng.run_frames(d_first, seed=seed, frame_offset=off, outputs=names, out=out, check=False)
             eng.mmse_full_apply_pilots(out["h_ls_pilots"], slots[0], W, out=out["H_mmse"], scratch=scr)
@@ -409,7 +437,10 @@ def run(args):
     if rank == 0:
         taps_ms, kern_ms = kern.get("taps_kernel", 0.0), kern.get("frame_kernel", 0.0)
         cfgd = {"workload": args.workload, "frames_per_step_per_gpu": F, "mimo": f"{T}x{R}", "fft_size": N, "pilots": P,
-                "pattern_group": group, "patterns": len(pils), "host_plan_build_s": round(t_plan, 2),
+                "pattern_group": group, "patterns": npatterns,
+                "pattern_source": ("device: Philox pilot selection + Delaunay + plan in one launch" + (", rebuilt inside every timed step" if per_step_patterns else ""))
+                if device_patterns else "host: legacy shuffle + Qhull",
+                "host_plan_build_s": round(t_plan, 2) if not device_patterns else 0.0, "plan_build_s": round(t_plan, 3),
                 "host_plan_workers": workers, "output_placement": placement, "rng": "Philox4x32-10 on device",
                 "outputs": names, "parallelism": f"frames sharded x{world}", "dist_backend": args.dist_backend if world > 1 else None}
         if kind == "dataset":
@@ -431,6 +462,8 @@ def run(args):
                         estimators="LS(linear)+MMSE(diag)")
         if group == 1 and kind != "fullcov":   # a plan of its own per frame has to be read: 16-B record per RE + 4-B pilot index
             bytes_frame += 16 * G + 4 * P
+        if "plan_kernels" in kern:
+            cfgd["plan_build_kernel_ms"] = kern["plan_kernels"]
         if kind == "fullcov":
             gemm_ms = kern.get("cgemm_w_kernel_3m", 0.0)
             flop = 8.0 * P * P * R * F                               # one right-hand side per (frame, rx): quirk Q9
@@ -476,7 +509,10 @@ def main():
     ap.add_argument("--pattern-group", type=int, default=PATTERN_GROUP,
                     help="frames sharing one pilot pattern + interpolation plan; 1 = a new random pattern per frame as the "
                          "reference draws them (plans built BEFORE the timed region)")
-    ap.add_argument("--plan-workers", type=int, default=0, help="host processes for plan building (0 = min(16, cores))")
+    ap.add_argument("--patterns", default="device", choices=["device", "host"],
+                    help="device: pilot patterns drawn, triangulated and planned on the GPU (default); host: legacy np.random "
+                         "shuffle + Qhull on the host cores")
+    ap.add_argument("--plan-workers", type=int, default=0, help="host processes for plan building with --patterns host (0 = min(16, cores))")
     ap.add_argument("--placement-tries", type=int, default=1,
                     help="candidate allocations per output tensor group (1 = take the first allocation, the default; "
                          ">1 probes placements with the real kernel and keeps the fastest)")

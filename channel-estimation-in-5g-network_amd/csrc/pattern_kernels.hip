@@ -47,26 +47,20 @@ struct PatBuildArgs {
     int32_t* status;
 };
 
-struct PatLds {
-    uint32_t* pts;                // [P] (row << 16 | col), ascending
-    uint16_t* tv[3];              // triangle vertices (pilot ordinals), counter-clockwise in (row, col)
-    uint16_t* tn[3];              // tn[i][t]: triangle across the edge opposite vertex i, TNONE on the hull
-    uint32_t* claim;              // [NT]
-    uint16_t* partner;            // [NT] TNONE = not flipped this round
-    int* misc;                    // small scalars / per-row tables
-};
-
 __device__ __forceinline__ int px_of(uint32_t v) { return (int)(v >> 16); }
 __device__ __forceinline__ int py_of(uint32_t v) { return (int)(v & 0xFFFFu); }
 __device__ __forceinline__ int orient2(uint32_t a, uint32_t b, uint32_t c) {
     return (px_of(b) - px_of(a)) * (py_of(c) - py_of(a)) - (py_of(b) - py_of(a)) * (px_of(c) - px_of(a));
 }
 // > 0 iff d lies strictly inside the circumcircle of the counter-clockwise triangle (a, b, c)
+// Coordinate differences are < 2^15, so every squared length and every 2x2 minor fits int32 and only the three final
+// products need 64 bits (one v_mad_i64_i32 each; a full 64 x 64 multiply costs a dozen quarter-rate instructions).
 __device__ __forceinline__ long long incircle(uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
-    const long long adx = px_of(a) - px_of(d), ady = py_of(a) - py_of(d), bdx = px_of(b) - px_of(d), bdy = py_of(b) - py_of(d),
-                    cdx = px_of(c) - px_of(d), cdy = py_of(c) - py_of(d);
-    return (adx * adx + ady * ady) * (bdx * cdy - cdx * bdy) - (bdx * bdx + bdy * bdy) * (adx * cdy - cdx * ady) +
-           (cdx * cdx + cdy * cdy) * (adx * bdy - bdx * ady);
+    const int adx = px_of(a) - px_of(d), ady = py_of(a) - py_of(d), bdx = px_of(b) - px_of(d), bdy = py_of(b) - py_of(d),
+              cdx = px_of(c) - px_of(d), cdy = py_of(c) - py_of(d);
+    const int al = adx * adx + ady * ady, bl = bdx * bdx + bdy * bdy, cl = cdx * cdx + cdy * cdy;
+    const int bc = bdx * cdy - cdx * bdy, ac = adx * cdy - cdx * ady, ab = adx * bdy - bdx * ady;
+    return (long long)al * (long long)bc - (long long)bl * (long long)ac + (long long)cl * (long long)ab;
 }
 // number of entries of the ascending array a[0..n) that are < key / <= key
 __device__ __forceinline__ int count_less(const uint32_t* a, int n, uint32_t key) {
@@ -80,32 +74,47 @@ __device__ __forceinline__ int count_leq(const uint32_t* a, int n, uint32_t key)
     return lo;
 }
 
-// exclusive scan of one value per thread over the workgroup; `scr` = PB_THREADS + 1 ints of LDS; returns (exclusive prefix, total)
+// exclusive scan of one value per thread over the workgroup (wave shuffles + one LDS hop); `scr` >= 8 ints of LDS;
+// returns (exclusive prefix, total)
 __device__ __forceinline__ int2 block_exscan(int v, int* scr) {
-    const int tid = threadIdx.x;
-    scr[tid] = v;
-    __syncthreads();
-    for (int off = 1; off < PB_THREADS; off <<= 1) {
-        const int t = tid >= off ? scr[tid - off] : 0;
-        __syncthreads();
-        scr[tid] += t;
-        __syncthreads();
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int incl = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int t = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += t;
     }
-    const int incl = scr[tid], tot = scr[PB_THREADS - 1];
+    if (lane == 63) scr[wave] = incl;
     __syncthreads();
-    return make_int2(incl - v, tot);
+    int base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < PB_THREADS / 64; ++w) { const int x = scr[w]; if (w < wave) base += x; tot += x; }
+    __syncthreads();
+    return make_int2(base + incl - v, tot);
 }
 
 size_t pattern_build_lds_bytes(int G, int Pcap) {
     const size_t tri = (size_t)4 * Pcap + (size_t)2 * Pcap * (6 * 2 + 4 + 2);        // pts | tv, tn | claim | partner
     const size_t keys = (size_t)4 * G;
-    return (tri > keys ? tri : keys) + (size_t)(PB_THREADS + 8 + 4 * (PB_MAX_ROWS + 2)) * sizeof(int) + 64;
+    return (tri > keys ? tri : keys) + (size_t)(PB_THREADS + 8 + 8 * (PB_MAX_ROWS + 2)) * sizeof(int) + 64;
 }
+
+#ifdef CHEST_STAMPS
+__device__ unsigned long long* g_pat_stamp = nullptr;           // [count][8] cycles of wave 0 per phase (diagnostic build only)
+#define PSTAMP(i) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
+                       if (tid == 0 && g_pat_stamp) g_pat_stamp[(size_t)blockIdx.x * 8 + (i)] = now_ - pst_; pst_ = now_; \
+                       __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define PSTAMP(i) do { } while (0)
+#endif
 
 __global__ void __launch_bounds__(PB_THREADS)
 pattern_build_kernel(const PatBuildArgs A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const int tid = threadIdx.x, j = blockIdx.x;
+#ifdef CHEST_STAMPS
+    unsigned long long pst_ = __builtin_amdgcn_s_memtime();
+#endif
     const int S = A.S, nsc = A.nsc, G = S * nsc;
     const int P = A.num_pilots[j];
     unsigned char* base = A.pool + (size_t)j * A.stride;
@@ -128,7 +137,11 @@ pattern_build_kernel(const PatBuildArgs A) {
     int* rowstart = misc + PB_THREADS + 8;                       // [rows + 1] first pilot of every row
     int* occ = rowstart + PB_MAX_ROWS + 2;                       // occupied rows
     int* toff = occ + PB_MAX_ROWS + 2;                           // first triangle of every strip
-    unsigned char* big = (unsigned char*)(toff + PB_MAX_ROWS + 2);
+    int* stack = toff + PB_MAX_ROWS + 2;                         // pocket scan (thread 0): chain stack,
+    uint32_t* eown = (uint32_t*)(stack + PB_MAX_ROWS + 2);       //   owner of the edge (stack[i-1], stack[i]): tri << 2 | slot, or ~0u,
+    int* eq = (int*)(eown + PB_MAX_ROWS + 2);                    //   strip of that edge if it is the bare chain edge of a strip without triangles,
+    uint32_t* rung = (uint32_t*)(eq + PB_MAX_ROWS + 2);          //   and who owns such an edge after the left pass
+    unsigned char* big = (unsigned char*)(rung + PB_MAX_ROWS + 2);
     big = (unsigned char*)(((uintptr_t)big + 15) & ~(uintptr_t)15);
     uint32_t* keys = (uint32_t*)big;
     uint32_t* pts = (uint32_t*)big;
@@ -156,22 +169,29 @@ pattern_build_kernel(const PatBuildArgs A) {
             if (g + 3 < G) keys[g + 3] = w.w;
         }
         __syncthreads();
-        // smallest threshold tau with #{key <= tau} >= P (bisection on the 32 bits; counts through one LDS counter)
-        uint32_t lo = 0, hi = 0xFFFFFFFFu;
-        while (lo < hi) {
-            const uint32_t mid = lo + ((hi - lo) >> 1);
-            if (tid == 0) cnt_s[0] = 0;
+        // tau = the P-th smallest key, by radix selection: four passes over 8-bit digits, most significant first; each pass
+        // histograms the digit of the keys that match the prefix found so far (LDS atomics), scans the 256 bins and keeps
+        // the bin in which the P-th key falls
+        uint32_t prefix = 0;
+        int need = P;                                                         // rank of tau among the keys matching the prefix
+        for (int shift = 24; shift >= 0; shift -= 8) {
+            scan[tid] = 0;                                                    // PB_THREADS == 256 bins
             __syncthreads();
-            int c = 0;
-            for (int g = g_lo; g < g_hi; ++g) c += keys[g] <= mid ? 1 : 0;
-            c = (int)wave_sum((float)c);                                      // <= 64 * per < 2^24: exact in float
-            if ((tid & 63) == 0) atomicAdd(&cnt_s[0], c);
+            for (int g = g_lo; g < g_hi; ++g) {
+                const uint32_t kq = keys[g];
+                if (shift == 24 || (kq >> (shift + 8)) == prefix) atomicAdd(&scan[(kq >> shift) & 255u], 1);
+            }
             __syncthreads();
-            const int tot = cnt_s[0];
+            const int h = scan[tid];
             __syncthreads();
-            if (tot >= P) hi = mid; else lo = mid + 1;
+            const int2 ex = block_exscan(h, scan);                            // keys in lower bins
+            if (ex.x < need && need <= ex.x + h) { cnt_s[0] = tid; cnt_s[4] = need - ex.x; }     // exactly one bin qualifies
+            __syncthreads();
+            prefix = (prefix << 8) | (uint32_t)cnt_s[0];
+            need = cnt_s[4];
+            __syncthreads();
         }
-        const uint32_t tau = lo;
+        const uint32_t tau = prefix;
         int nl = 0, ne = 0;
         for (int g = g_lo; g < g_hi; ++g) { nl += keys[g] < tau ? 1 : 0; ne += keys[g] == tau ? 1 : 0; }
         const int2 sl = block_exscan(nl, scan);
@@ -194,17 +214,21 @@ pattern_build_kernel(const PatBuildArgs A) {
     }
     __syncthreads();
 
+    PSTAMP(0);                                                   // pilot selection
     // ================= 2. slot table ==============================================================================
     {
         int g = g_lo;
         int s = g / nsc, k = g - s * nsc;
+        int pos = g < g_hi ? count_less(pts, P, ((uint32_t)s << 16) | (uint32_t)k) : 0;      // pilots before the block
+        uint32_t nextp = pos < P ? pts[pos] : 0xFFFFFFFFu;
         for (; g < g_hi; ++g) {
             const uint32_t key = ((uint32_t)s << 16) | (uint32_t)k;
-            const int pos = count_less(pts, P, key);
-            slotp[g] = (uint16_t)((pos < P && pts[pos] == key) ? pos : P + (g - pos));
+            if (key == nextp) { slotp[g] = (uint16_t)pos; ++pos; nextp = pos < P ? pts[pos] : 0xFFFFFFFFu; }
+            else slotp[g] = (uint16_t)(P + (g - pos));
             if (++k == nsc) { k = 0; ++s; }
         }
     }
+    PSTAMP(1);                                                   // slot table
     if (A.method < 0) return;                                    // simulation-only pattern: no plan
 
     // per-row tables
@@ -243,6 +267,7 @@ pattern_build_kernel(const PatBuildArgs A) {
     }
 
     // ================= 3. initial triangulation ====================================================================
+    PSTAMP(2);                                                   // row tables
     const int nstrip = cnt_s[2];
     // every pilot emits the triangle that advances from it to its right-hand neighbour in its row: once as a point of the
     // upper row of the strip below it (A-step) and once as a point of the lower row of the strip above it (B-step)
@@ -292,75 +317,94 @@ pattern_build_kernel(const PatBuildArgs A) {
         }
     }
     __syncthreads();
-    // pockets between the end chains and the convex hull (one thread; <= 2 (m - 2) triangles)
+    PSTAMP(3);                                                   // strips
+    // pockets between the end chains and the convex hull (one thread; <= 2 (m - 2) triangles).  A monotone-chain scan over the
+    // first (left) / last (right) pilot of every occupied row; every boundary edge of the scan carries its owner (triangle,
+    // slot), so each pocket triangle is linked to its neighbours in O(1).
     if (tid == 0) {
         int nt = nstrip;
-        const int first_pocket = nt;
-        int stack[PB_MAX_ROWS + 1];
+        auto link = [&](uint32_t own, int t, int c) {            // make `own` and slot c of triangle t neighbours
+            if (own == 0xFFFFFFFFu) return;
+            TN(c)[t] = (uint16_t)(own >> 2);
+            TN((int)(own & 3u))[own >> 2] = (uint16_t)t;
+        };
+        auto slot_of_edge = [&](int t, uint32_t x, uint32_t y) -> int {     // slot of t whose edge joins x and y
+            for (int d = 0; d < 3; ++d) {
+                const uint32_t e0 = TV((d + 1) % 3)[t], e1 = TV((d + 2) % 3)[t];
+                if ((e0 == x && e1 == y) || (e0 == y && e1 == x)) return d;
+            }
+            return 0;
+        };
+        for (int q = 0; q < m; ++q) rung[q] = 0xFFFFFFFFu;
         for (int side = 0; side < 2; ++side) {
             int sp = 0;
             for (int q = 0; q < m; ++q) {
                 const int r = occ[q];
                 const int p = side == 0 ? rowstart[r] : rowstart[r + 1] - 1;
+                // owner of the chain edge (previous chain point, p): the first / last triangle of strip q - 1
+                uint32_t cur = 0xFFFFFFFFu;
+                if (q > 0) {
+                    const int nq = toff[q] - toff[q - 1];
+                    if (nq > 0) {
+                        const int te = side == 0 ? toff[q - 1] : toff[q - 1] + nq - 1;
+                        cur = ((uint32_t)te << 2) | (uint32_t)slot_of_edge(te, (uint32_t)stack[sp - 1], (uint32_t)p);
+                    } else cur = rung[q - 1];                    // both rows hold one pilot: the edge belongs to both chains
+                }
+                const bool empty_strip = q > 0 && toff[q] - toff[q - 1] <= 0;
+                int cur_q = empty_strip ? q - 1 : -1;            // cur is still the bare chain edge of that (triangle-less) strip
                 while (sp >= 2) {
                     const int a = stack[sp - 2], b = stack[sp - 1];
                     const int o = orient2(pts[a], pts[b], pts[p]);
                     // b lies in a pocket if it is on the inner side of a -> p (left chain: o < 0, right chain: o > 0)
-                    if (side == 0 ? o < 0 : o > 0) {
-                        // counter-clockwise: (a, p, b) on the left chain, (a, b, p) on the right one
-                        tv0[nt] = (uint16_t)a; tv1[nt] = (uint16_t)(side == 0 ? p : b); tv2[nt] = (uint16_t)(side == 0 ? b : p);
-                        tn0[nt] = tn1[nt] = tn2[nt] = (uint16_t)TNONE;
-                        ++nt; --sp;
-                    } else break;
+                    if (!(side == 0 ? o < 0 : o > 0)) break;
+                    // counter-clockwise: (a, p, b) on the left chain, (a, b, p) on the right one
+                    const int t = nt++;
+                    tv0[t] = (uint16_t)a; tv1[t] = (uint16_t)(side == 0 ? p : b); tv2[t] = (uint16_t)(side == 0 ? b : p);
+                    tn0[t] = tn1[t] = tn2[t] = (uint16_t)TNONE;
+                    const int s_ab = side == 0 ? 1 : 2;          // edge (a, b) is opposite p
+                    const int s_bp = 0;                          // edge (b, p) is opposite a
+                    const int s_ap = side == 0 ? 2 : 1;          // edge (a, p) is opposite b
+                    link(eown[sp - 1], t, s_ab);
+                    link(cur, t, s_bp);
+                    // a chain edge shared by both chains (strip without triangles): remember who took it on the left pass
+                    if (side == 0 && eq[sp - 1] >= 0) rung[eq[sp - 1]] = ((uint32_t)t << 2) | (uint32_t)s_ab;
+                    if (side == 0 && cur_q >= 0) rung[cur_q] = ((uint32_t)t << 2) | (uint32_t)s_bp;
+                    cur_q = -1;
+                    cur = ((uint32_t)t << 2) | (uint32_t)s_ap;
+                    --sp;
                 }
+                eown[sp] = cur;
+                eq[sp] = cur_q;
                 stack[sp++] = p;
-            }
-        }
-        // adjacency of the pocket triangles: against each other, and against the end triangles of the strips
-        for (int t = first_pocket; t < nt; ++t) {
-            for (int c = 0; c < 3; ++c) {
-                const uint32_t x = TV((c + 1) % 3)[t], y = TV((c + 2) % 3)[t];
-                uint32_t found = TNONE;
-                int fslot = 0;
-                for (int u = first_pocket; u < nt && found == TNONE; ++u) {
-                    if (u == t) continue;
-                    for (int d = 0; d < 3; ++d)
-                        if (TV((d + 1) % 3)[u] == y && TV((d + 2) % 3)[u] == x) { found = (uint32_t)u; fslot = d; }
-                }
-                if (found == TNONE) {
-                    // a chain edge between consecutive occupied rows: the first / last triangle of that strip
-                    for (int q = 0; q + 1 < m && found == TNONE; ++q) {
-                        const int nq = toff[q + 1] - toff[q];
-                        if (nq <= 0) continue;
-                        const int cand[2] = {toff[q], toff[q] + nq - 1};
-                        for (int e = 0; e < 2 && found == TNONE; ++e)
-                            for (int d = 0; d < 3; ++d)
-                                if (TV((d + 1) % 3)[cand[e]] == y && TV((d + 2) % 3)[cand[e]] == x && TN(d)[cand[e]] == TNONE) {
-                                    found = (uint32_t)cand[e]; fslot = d;
-                                }
-                    }
-                }
-                if (found != TNONE) { TN(c)[t] = (uint16_t)found; TN(fslot)[found] = (uint16_t)t; }
             }
         }
         cnt_s[2] = nt;
     }
     __syncthreads();
     const int ntri = cnt_s[2];
+    PSTAMP(4);                                                   // pockets
 
     // ================= 4. Lawson flips ==============================================================================
+    // Rounds of independent flips.  A triangle is ACTIVE (its claim word starts the round as CLAIM_DIRTY) if it changed or lost a
+    // claim in the previous round; everything is active at first.  Only active triangles test their edges -- an edge between
+    // two active triangles from the smaller index -- so once the bulk of the flips is done a round costs one cheap pass.
+    // Every thread keeps the active set of its own triangles (t = tid + 256 i) as a register bit mask.
+    constexpr uint32_t CLAIM_NONE = 0xFFFFFFFFu, CLAIM_DIRTY = 0xFFFFFFFEu;
+    uint32_t active = 0;
+    for (int i = 0, t = tid; t < ntri; t += PB_THREADS, ++i) { claim[t] = CLAIM_DIRTY; partner[t] = (uint16_t)TNONE; active |= 1u << i; }
+    __syncthreads();
     for (int round = 0; round < 4 * NT + 64; ++round) {
-        for (int t = tid; t < ntri; t += PB_THREADS) { claim[t] = 0xFFFFFFFFu; partner[t] = (uint16_t)TNONE; }
         if (tid == 0) cnt_s[3] = 0;
         __syncthreads();
-        // phase 0: every interior edge (t < u) that fails the in-circle test claims both of its triangles
-        for (int t = tid; t < ntri; t += PB_THREADS) {
-            const uint32_t v[3] = {tv0[t], tv1[t], tv2[t]};
+        // phase 0: active triangles test their edges; an edge that fails the in-circle test claims both of its triangles
+        for (uint32_t m = active; m != 0; m &= m - 1) {
+            const int t = tid + PB_THREADS * (__ffs(m) - 1);
             const uint32_t n[3] = {tn0[t], tn1[t], tn2[t]};
+            const uint32_t v[3] = {tv0[t], tv1[t], tv2[t]};
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
                 const uint32_t u = n[i];
-                if (u == TNONE || u < (uint32_t)t) continue;
+                if (u == TNONE || (u < (uint32_t)t && claim[u] != CLAIM_NONE)) continue;      // the other (active) side tests it
                 const uint32_t b = v[(i + 1) % 3], c = v[(i + 2) % 3];
                 const uint32_t u0 = tv0[u], u1 = tv1[u], u2 = tv2[u];
                 const uint32_t d = (u0 != b && u0 != c) ? u0 : ((u1 != b && u1 != c) ? u1 : u2);
@@ -374,10 +418,12 @@ pattern_build_kernel(const PatBuildArgs A) {
         }
         __syncthreads();
         if (cnt_s[3] == 0) break;
-        // phase 1: winners rewrite their two triangles; outer neighbours keep their OLD ids for now
-        for (int t = tid; t < ntri; t += PB_THREADS) {
+        // phase 1: winners (an edge that holds the claim on both of its triangles) rewrite the two triangles; outer neighbours
+        // keep their OLD ids for now
+        for (uint32_t m = active; m != 0; m &= m - 1) {
+            const int t = tid + PB_THREADS * (__ffs(m) - 1);
             const uint32_t key = claim[t];
-            if ((key >> 2) != (uint32_t)t) continue;             // the winning edge of t belongs to another (smaller) triangle, or none
+            if ((key >> 2) != (uint32_t)t) continue;             // the winning edge of t was tested from another triangle, or none
             const int i = (int)(key & 3u);
             const uint32_t u = TN(i)[t];
             if (claim[u] != key) continue;
@@ -395,32 +441,50 @@ pattern_build_kernel(const PatBuildArgs A) {
             partner[t] = (uint16_t)u; partner[u] = (uint16_t)t;
         }
         __syncthreads();
-        // phase 2: every new triangle resolves its outer neighbours (the old neighbour, or its partner if that one flipped
-        // too) and writes the back-pointer of neighbours that did not flip
-        for (int X = tid; X < ntri; X += PB_THREADS) {
-            const uint32_t pX = partner[X];
-            if (pX == TNONE) continue;
+        // phase 2: the owner of every flip resolves the outer neighbours of its two new triangles (the old neighbour, or its
+        // partner if that one flipped too) and writes the back-pointer of neighbours that did not flip
+        for (uint32_t m = active; m != 0; m &= m - 1) {
+            const int t = tid + PB_THREADS * (__ffs(m) - 1);
+            const uint32_t pT = partner[t];
+            if (pT == TNONE || (claim[t] >> 2) != (uint32_t)t) continue;
 #pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                uint32_t Y = TN(k)[X];
-                if (Y == TNONE || Y == pX) continue;
-                const uint32_t x = TV((k + 1) % 3)[X], y = TV((k + 2) % 3)[X];
-                const uint32_t pY = partner[Y];
-                if (pY != TNONE) {
-                    const uint32_t y0 = tv0[Y], y1 = tv1[Y], y2 = tv2[Y];
-                    const bool has = (y0 == x || y1 == x || y2 == x) && (y0 == y || y1 == y || y2 == y);
-                    if (!has) Y = pY;
-                    TN(k)[X] = (uint16_t)Y;
-                } else {
-                    const uint32_t y0 = tv0[Y], y1 = tv1[Y];
-                    const int k2 = (y0 != x && y0 != y) ? 0 : ((y1 != x && y1 != y) ? 1 : 2);
-                    TN(k2)[Y] = (uint16_t)X;
+            for (int side = 0; side < 2; ++side) {
+                const int X = side == 0 ? t : (int)pT;
+                const uint32_t pX = side == 0 ? pT : (uint32_t)t;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    uint32_t Y = TN(k)[X];
+                    if (Y == TNONE || Y == pX) continue;
+                    const uint32_t x = TV((k + 1) % 3)[X], y = TV((k + 2) % 3)[X];
+                    const uint32_t pY = partner[Y];
+                    if (pY != TNONE) {
+                        const uint32_t y0 = tv0[Y], y1 = tv1[Y], y2 = tv2[Y];
+                        const bool has = (y0 == x || y1 == x || y2 == x) && (y0 == y || y1 == y || y2 == y);
+                        if (!has) Y = pY;
+                        TN(k)[X] = (uint16_t)Y;
+                    } else {
+                        const uint32_t y0 = tv0[Y], y1 = tv1[Y];
+                        const int k2 = (y0 != x && y0 != y) ? 0 : ((y1 != x && y1 != y) ? 1 : 2);
+                        TN(k2)[Y] = (uint16_t)X;
+                    }
                 }
             }
         }
         __syncthreads();
+        // claimed triangles (flipped, or candidates that lost) are the next round's active set; marks that drew no claim clear
+        active = 0;
+        for (int i = 0, t = tid; t < ntri; t += PB_THREADS, ++i) {
+            const uint32_t c = claim[t];
+            if (c == CLAIM_NONE) continue;
+            const bool act = c < CLAIM_DIRTY;
+            claim[t] = act ? CLAIM_DIRTY : CLAIM_NONE;
+            partner[t] = (uint16_t)TNONE;
+            if (act) active |= 1u << i;
+        }
+        __syncthreads();
     }
 
+    PSTAMP(5);                                                   // flips
     if (A.simp_out != nullptr) {
         int32_t* so = A.simp_out + (size_t)j * 2 * A.Pcap * 3;
         for (int t = tid; t < ntri; t += PB_THREADS) { so[3 * t] = tv0[t]; so[3 * t + 1] = tv1[t]; so[3 * t + 2] = tv2[t]; }
@@ -428,54 +492,72 @@ pattern_build_kernel(const PatBuildArgs A) {
     }
 
     // ================= 5. plan: walk to the containing triangle =====================================================
-    {
+    // Every lane owns a run of consecutive elements and runs ONE loop in which an iteration either crosses into the
+    // neighbouring triangle or emits the current element and moves one column on (lanes do not wait for each other per
+    // element).  While the triangle stays the same the three edge functions are updated incrementally (they are affine in
+    // the column); they are recomputed only after a crossing.
+    if (ntri > 0) {
         int g = g_lo;
         int s = g / nsc, k = g - s * nsc;
-        int t = ntri > 0 ? (int)(((long long)g_lo * ntri) / (G > 0 ? G : 1)) : 0;     // strips are laid out in element order
-        for (; g < g_hi; ++g) {
-            PlanRec rec{0.f, 0.f, 0u, 0u};
-            if (ntri > 0) {
+        int t = (int)(((long long)g_lo * ntri) / (G > 0 ? G : 1));                     // strips are laid out in element order
+        uint32_t i0 = 0, i1 = 0, i2 = 0;
+        int o0 = 0, o1 = 0, o2 = 0, d0 = 0, d1 = 0, d2 = 0;
+        bool fresh = true;                                        // triangle t not loaded yet
+        int since = 0;                                            // crossings since the last emitted element
+        while (g < g_hi) {
+            if (fresh) {
+                i0 = tv0[t]; i1 = tv1[t]; i2 = tv2[t];
+                const uint32_t a = pts[i0], b = pts[i1], c = pts[i2], q = ((uint32_t)s << 16) | (uint32_t)k;
+                o0 = orient2(b, c, q); o1 = orient2(c, a, q); o2 = orient2(a, b, q);
+                d0 = px_of(c) - px_of(b); d1 = px_of(a) - px_of(c); d2 = px_of(b) - px_of(a);   // d(orient(u, v, q)) / d(column of q) = v.x - u.x
+                fresh = false;
+            }
+            uint32_t nx = TNONE;
+            bool cross = false;
+            if (o0 < 0) { nx = tn0[t]; cross = true; }
+            else if (o1 < 0) { nx = tn1[t]; cross = true; }
+            else if (o2 < 0) { nx = tn2[t]; cross = true; }
+            if (cross && nx != TNONE && since <= ntri + 8) { t = (int)nx; fresh = true; ++since; continue; }
+            PlanRec rec{0.f, 0.f, 0u, 0u};                        // leaving through a hull edge: outside the convex hull
+            if (!cross) {
+                const float den = (float)(o0 + o1 + o2);
+                rec.w0 = (float)o0 / den; rec.w1 = (float)o1 / den;
+                rec.i01 = i0 | (i1 << 16); rec.i2v = i2 | (1u << 16);
+            } else if (nx != TNONE) {
+                // not reached on a Delaunay triangulation (the visibility walk is acyclic); exhaustive scan as a safety net
                 const uint32_t q = ((uint32_t)s << 16) | (uint32_t)k;
-                bool found = false, outside = false;
-                for (int step = 0; step < ntri + 8 && !found && !outside; ++step) {
-                    const uint32_t i0 = tv0[t], i1 = tv1[t], i2 = tv2[t];
-                    const uint32_t a = pts[i0], b = pts[i1], c = pts[i2];
-                    const int o0 = orient2(b, c, q), o1 = orient2(c, a, q), o2 = orient2(a, b, q);
-                    uint32_t nx = TNONE;
-                    bool cross = false;
-                    if (o0 < 0) { nx = tn0[t]; cross = true; }
-                    else if (o1 < 0) { nx = tn1[t]; cross = true; }
-                    else if (o2 < 0) { nx = tn2[t]; cross = true; }
-                    if (!cross) {
-                        const float den = (float)(o0 + o1 + o2);
-                        rec.w0 = (float)o0 / den; rec.w1 = (float)o1 / den;
-                        rec.i01 = i0 | (i1 << 16); rec.i2v = i2 | (1u << 16);
-                        found = true;
-                    } else if (nx == TNONE) outside = true;      // the way out crosses a hull edge: outside the convex hull
-                    else t = (int)nx;
-                }
-                if (!found && !outside) {
-                    // not reached on a Delaunay triangulation (the visibility walk is acyclic); exhaustive scan as a safety net
-                    for (int u = 0; u < ntri; ++u) {
-                        const uint32_t i0 = tv0[u], i1 = tv1[u], i2 = tv2[u];
-                        const int o0 = orient2(pts[i1], pts[i2], q), o1 = orient2(pts[i2], pts[i0], q), o2 = orient2(pts[i0], pts[i1], q);
-                        if ((o0 | o1 | o2) >= 0) {
-                            const float den = (float)(o0 + o1 + o2);
-                            rec.w0 = (float)o0 / den; rec.w1 = (float)o1 / den;
-                            rec.i01 = i0 | (i1 << 16); rec.i2v = i2 | (1u << 16);
-                            t = u;
-                            break;
-                        }
+                for (int u = 0; u < ntri; ++u) {
+                    const uint32_t j0 = tv0[u], j1 = tv1[u], j2 = tv2[u];
+                    const int p0 = orient2(pts[j1], pts[j2], q), p1 = orient2(pts[j2], pts[j0], q), p2 = orient2(pts[j0], pts[j1], q);
+                    if ((p0 | p1 | p2) >= 0) {
+                        const float den = (float)(p0 + p1 + p2);
+                        rec.w0 = (float)p0 / den; rec.w1 = (float)p1 / den;
+                        rec.i01 = j0 | (j1 << 16); rec.i2v = j2 | (1u << 16);
+                        break;
                     }
                 }
             }
             plan[g] = rec;
-            if (++k == nsc) { k = 0; ++s; }
+            ++g; since = 0;
+            if (++k == nsc) {                                     // next row: far from here, start again from the layout guess
+                k = 0; ++s;
+                t = (int)(((long long)g * ntri) / G);
+                fresh = true;
+            } else { o0 += d0; o1 += d1; o2 += d2; }
         }
+    } else {
+        for (int g = g_lo; g < g_hi; ++g) plan[g] = PlanRec{0.f, 0.f, 0u, 0u};
     }
+    PSTAMP(6);                                                   // plan walk
 }
 
 }  // namespace chest
+
+#ifdef CHEST_STAMPS
+extern "C" int chest_debug_set_pattern_stamp_buffer(void* dev_ptr) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(chest::g_pat_stamp), &dev_ptr, sizeof(void*)) == hipSuccess ? 0 : -2;
+}
+#endif
 
 using namespace chest;
 
@@ -500,7 +582,7 @@ extern "C" int chest_patterns_build(chest_ctx* ctx, void* stream, int32_t first_
         }
         Pmax = num_pilots[i] > Pmax ? num_pilots[i] : Pmax;
     }
-    if (Pmax >= 0xFFFF / 2) { set_error("chest_patterns_build: at most 32766 pilots per pattern"); return CHEST_EINVAL; }
+    if (2 * Pmax > 32 * PB_THREADS) { set_error("chest_patterns_build: at most %d pilots per pattern", 16 * PB_THREADS); return CHEST_EINVAL; }
     const size_t lds = pattern_build_lds_bytes(G, Pmax);
     if (lds > 160 * 1024) {
         set_error("chest_patterns_build: %d pilots need %zu B of LDS (> 160 KiB); use chest_pattern_set_triangulation for such patterns", Pmax, lds);

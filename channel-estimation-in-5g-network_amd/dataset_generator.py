@@ -21,7 +21,6 @@ import numpy as np
 
 from . import channel_simulator as _cs
 from . import engine as _engine
-from . import interp_plan as _interp_plan
 from . import sharding as _sharding
 
 CHANNEL_NAMES = ("EPA", "EVA", "ETU")
@@ -93,17 +92,23 @@ class ChannelEstimationDataset:
 
     # ---- native batch path ------------------------------------------------------------------------
     def generate_dataset_native(self, num_samples: int, seed: int = 42, rank: int = 0, world: int = 1,
-                                batch_frames: int = 4096, pattern_group: int = 1024, with_mmse: bool = True,
+                                batch_frames: int = 4096, pattern_group: int = 1, with_mmse: bool = True,
                                 channel_types=None, doppler_values=None, snr_values=None, pilot_densities=None,
-                                to_numpy: bool = True, plan_workers: int = 0, _range=None) -> Dict:
+                                to_numpy: bool = True, host_budget_gb: float = 16.0, _range=None) -> Dict:
         """Frames [begin, end) of this rank out of ``num_samples``, on the device RNG.
 
-        Per-frame parameters are counter-based choices (``sharding.frame_choices``) from the same value
-        lists the reference samples from; one pilot pattern (legacy shuffle seeded by seed, density,
-        group) is shared by each group of ``pattern_group`` consecutive global frames.  Returns the
-        stacked record of ``run_phase3_dataset_generation.py:193-205`` plus ``H_mmse``, ``frame_index``
-        and the fused ``metrics``.
-        """
+        Per-frame parameters are counter-based choices (``sharding.frame_choices``) from the same value lists the
+        reference samples from.  ``pattern_group = 1`` (default) draws a NEW pilot pattern for every frame, as the
+        reference does inside every ``simulate_transmission`` (src/channel_simulator.py:390-391): pilots, Delaunay
+        triangulation and interpolation plan of a whole batch are built on the device in one launch
+        (``Engine.build_patterns``), keyed by (seed, global frame index).  ``pattern_group = n`` shares one pattern among
+        n consecutive global frames of equal density.  Returns the stacked record of
+        ``run_phase3_dataset_generation.py:193-205`` plus ``H_mmse``, ``frame_index``, ``frame_status`` and the fused
+        ``metrics``; frames whose descriptor the device rejected (status != 0) are dropped from the record and reported,
+        as the reference skips a failed sample (src/dataset_generator.py:120-125).
+
+        The record is accumulated on the host (``to_numpy``) or the device; a shard that would exceed ``host_budget_gb``
+        is refused -- use ``generate_dataset_native_to_files``, which streams chunk files instead."""
         import torch
         geom = _geometry_from_config(self.config)
         eng = _engine.get_engine(geom)
@@ -114,6 +119,10 @@ class ChannelEstimationDataset:
         pilot_densities = list(pilot_densities or self.config['pilots']['density'])
         begin, end = _range if _range is not None else _sharding.shard_range(num_samples, rank, world)
         n = end - begin
+        per_frame = 8 * S * nsc * (T + R + R * T * (2 + int(with_mmse))) + 4 * S * nsc + 64
+        if n * per_frame > host_budget_gb * 2**30:
+            raise MemoryError(f"this shard is {n * per_frame / 2**30:.1f} GiB (> host_budget_gb = {host_budget_gb}); "
+                              "stream it with generate_dataset_native_to_files or raise the budget")
         idx = np.arange(begin, end, dtype=np.int64)
         ci, di, si, pi = _sharding.frame_choices(seed, idx, (len(channel_types), len(doppler_values),
                                                              len(snr_values), len(pilot_densities)))
@@ -121,46 +130,47 @@ class ChannelEstimationDataset:
         fd = np.asarray(doppler_values, dtype=np.float32)[di]
         snr = np.asarray(snr_values, dtype=np.float32)[si]
         dens = np.asarray(pilot_densities, dtype=np.float64)[pi]
-        group = idx // pattern_group
-        slots = np.empty(n, dtype=np.int32)
-        keys = sorted(set(zip(pi.tolist(), group.tolist())))
-        pils = []
-        for key in keys:
-            d = float(pilot_densities[key[0]])
-            rs = np.random.RandomState((int(seed) * 1000003 + key[1] * 101 + key[0]) % (2**32))
-            perm = np.arange(G)
-            rs.shuffle(perm)                                                         # PilotPattern's algorithm (:227-229)
-            pils.append(np.sort(perm[: int(G * d)]))
-        # Qhull triangulations (~2 ms per pattern per core) optionally in a process pool; the device turns them into plans,
-        # and each upload overlaps the pool's remaining work
-        plans = _interp_plan.triangulations_iter(pils, S, nsc, plan_workers) if plan_workers > 1 else iter([None] * len(pils))
-        eng.max_cached_patterns = max(eng.max_cached_patterns, len(keys) + 8)
-        for key, pil, plan in zip(keys, pils, plans):
-            slots[(pi == key[0]) & (group == key[1])] = eng.pattern_slot(pil, "linear", plan=plan)
-        names = ["tx", "rx", "H", "H_ls", "pilot_mask", "metrics"] + (["H_mmse"] if with_mmse else [])
+        npil_of_density = np.asarray([int(G * float(d)) for d in pilot_densities], dtype=np.int32)
+        pattern_group = max(1, int(pattern_group))
+        # pattern id of a frame: the global frame index itself when every frame has its own pattern, else (group, density)
+        pat_id = idx.astype(np.uint64) if pattern_group == 1 else \
+            ((idx // pattern_group) * len(pilot_densities) + pi).astype(np.uint64)
+        names = ["tx", "rx", "H", "H_ls", "pilot_mask_f32", "metrics", "frame_status"] + (["H_mmse"] if with_mmse else [])
         chunks = {k: [] for k in names}
         for b0 in range(0, n, batch_frames):
             b1 = min(n, b0 + batch_frames)
-            descs = _engine.make_descs(ctype[b0:b1], fd[b0:b1], snr[b0:b1], slots[b0:b1], n=b1 - b0)
+            ids, inv = np.unique(pat_id[b0:b1], return_inverse=True)
+            first = np.zeros(len(ids), dtype=np.int64); first[inv[::-1]] = np.arange(b1 - b0)[::-1]     # a frame of each pattern
+            slots = eng.build_patterns(0, npil_of_density[pi[b0:b1][first]], seed=seed, pattern_ids=ids, method="linear")
+            descs = _engine.make_descs(ctype[b0:b1], fd[b0:b1], snr[b0:b1], slots[inv], n=b1 - b0)
             out = eng.run_frames(descs, seed=seed, frame_offset=int(begin + b0), outputs=names)
-            out["pilot_mask"] = out["pilot_mask"].to(torch.float32)           # reference schema: f32 mask; converted on the device
             for k in names:
                 chunks[k].append(out[k].cpu().numpy() if to_numpy else out[k])
         # host side stays in NumPy: CPU-tensor ops would start torch's intra-op thread pool (see engine._dev)
         if to_numpy:
             cat = {k: (np.concatenate(v) if v else np.empty(0)) for k, v in chunks.items()}
+            status = np.asarray(cat["frame_status"], dtype=np.uint8)
         else:
             cat = {k: (torch.cat(v) if v else torch.empty(0)) for k, v in chunks.items()}
-        conv = lambda t: t
+            status = cat["frame_status"].cpu().numpy() if n else np.zeros(0, np.uint8)
+        ok = status == 0
+        for i in np.nonzero(~ok)[0]:
+            print(f"Warning: Failed to generate sample {int(idx[i])}: device status {int(status[i])}")
+        keep = (lambda a: a[ok]) if (n and not ok.all()) else (lambda a: a)
+        if not to_numpy and n and not ok.all():
+            okt = torch.from_numpy(ok).to(cat["rx"].device)
+            keep_t = lambda t: t[okt]
+        else:
+            keep_t = keep
         rec = {
-            'rx_symbols': conv(cat["rx"]), 'tx_symbols': conv(cat["tx"]), 'H_ls': conv(cat["H_ls"]),
-            'H_true': conv(cat["H"]), 'pilot_mask': conv(cat["pilot_mask"]),
-            'snr_db': snr.astype(np.float32), 'channel_type': np.asarray(CHANNEL_NAMES)[ctype].astype('U3'),
-            'doppler_hz': fd.astype(np.float32), 'pilot_density': dens.astype(np.float32),
-            'frame_index': idx, 'metrics': conv(cat["metrics"]),
+            'rx_symbols': keep_t(cat["rx"]), 'tx_symbols': keep_t(cat["tx"]), 'H_ls': keep_t(cat["H_ls"]),
+            'H_true': keep_t(cat["H"]), 'pilot_mask': keep_t(cat["pilot_mask_f32"]),
+            'snr_db': keep(snr.astype(np.float32)), 'channel_type': keep(np.asarray(CHANNEL_NAMES)[ctype].astype('U3')),
+            'doppler_hz': keep(fd.astype(np.float32)), 'pilot_density': keep(dens.astype(np.float32)),
+            'frame_index': keep(idx), 'metrics': keep_t(cat["metrics"]), 'frame_status': status,
         }
         if with_mmse:
-            rec['H_mmse'] = conv(cat["H_mmse"])
+            rec['H_mmse'] = keep_t(cat["H_mmse"])
         return rec
 
     def generate_dataset_native_to_files(self, num_samples: int, out_dir: str, split: str = 'train', seed: int = 42,
@@ -168,8 +178,11 @@ class ChannelEstimationDataset:
                                          compressed: bool = True, **kwargs) -> Dict:
         """Stream this rank's frame range to chunk files ``{split}_rank{rank:02d}_chunk{id:04d}.npz`` (the reference's
         ``checkpoints/{split}_chunk_{id:04d}.npz`` scheme, run_phase3_robust.py:99-101, one series per rank) plus a JSON
-        manifest.  Chunks already on disk are skipped: with counter-based RNG a resumed run produces exactly the frames
-        an uninterrupted run would (the reference re-seeds on resume, run_phase3_robust.py:144-156, and does not).
+        manifest.  Chunks already on disk are skipped ONLY if they were written by the same job: every chunk stores the
+        generation parameters (seed, num_samples, chunk_frames, pattern_group, value lists, ...) and its ``frame_index``;
+        a chunk whose parameters or frame range differ from this call's is regenerated and overwritten.  With
+        counter-based RNG a resumed run then produces exactly the frames an uninterrupted run would (the reference
+        re-seeds on resume, run_phase3_robust.py:144-156, and does not).
         A 1 M-frame dataset is ~1.1 TB.  Deflating a chunk takes far longer than generating it (zlib manages ~0.1 GB/s
         per core against 4.5 GB per 4 096-frame chunk), so ``writers`` background threads compress and write finished
         chunks (zlib releases the GIL) while the GPU produces the next ones; at most ``writers + 1`` chunks are held on
@@ -178,9 +191,17 @@ class ChannelEstimationDataset:
         import os
         os.makedirs(out_dir, exist_ok=True)
         begin, end = _sharding.shard_range(num_samples, rank, world)
-        manifest = {"split": split, "seed": seed, "rank": rank, "world": world, "begin": begin, "end": end,
-                    "chunk_frames": chunk_frames, "chunks": []}
-        records = []
+        lists = {k: list(kwargs.get(k) or d) for k, d in (
+            ("channel_types", self.channel_config['models']), ("doppler_values", self.channel_config['doppler_hz']),
+            ("snr_values", self.config['simulation']['snr_range']), ("pilot_densities", self.config['pilots']['density']))}
+        g = _geometry_from_config(self.config)
+        params = {"seed": int(seed), "num_samples": int(num_samples), "chunk_frames": int(chunk_frames), "world": int(world),
+                  "pattern_group": int(kwargs.get("pattern_group", 1)), "with_mmse": bool(kwargs.get("with_mmse", True)),
+                  "geometry": [g.fft_size, g.cp_length, g.num_symbols, g.useful_subcarriers, g.num_tx, g.num_rx],
+                  **{k: [str(x) if isinstance(x, str) else float(x) for x in v] for k, v in lists.items()}}
+        params_json = json.dumps(params, sort_keys=True)
+        manifest = {"split": split, "rank": rank, "begin": begin, "end": end, "params": params, "chunks": [], "regenerated": []}
+        records, frame_ids = [], []
         from concurrent.futures import ThreadPoolExecutor
         pool = ThreadPoolExecutor(max_workers=max(1, int(writers)))
         pending = []
@@ -190,34 +211,55 @@ class ChannelEstimationDataset:
             (np.savez_compressed if compressed else np.savez)(tmp, **rec)
             os.replace(tmp, path)
 
+        def _load_if_same_job(path, b0, b1):
+            """The per-frame records of an existing chunk, or None when it is not this job's chunk [b0, b1)."""
+            try:
+                with np.load(path) as z:
+                    if "gen_params" not in z.files or str(z["gen_params"]) != params_json:
+                        return None
+                    fi = z["frame_index"]
+                    st = z["frame_status"] if "frame_status" in z.files else np.zeros(b1 - b0, np.uint8)
+                    want = np.arange(b0, b1, dtype=np.int64)[st == 0] if len(st) == b1 - b0 else None
+                    if want is None or not np.array_equal(fi, want):
+                        return None
+                    return {k: z[k] for k in ("frame_index", "snr_db", "doppler_hz", "pilot_density", "channel_type", "metrics")}
+            except Exception:
+                return None                                        # truncated / unreadable: regenerate
+
         for cid, b0 in enumerate(range(begin, end, chunk_frames)):
             b1 = min(end, b0 + chunk_frames)
             path = os.path.join(out_dir, f"{split}_rank{rank:02d}_chunk{cid:04d}.npz")
             manifest["chunks"].append({"file": os.path.basename(path), "first_frame": b0, "frames": b1 - b0})
-            if os.path.exists(path):                                               # exact resume
-                with np.load(path) as z:
-                    rec = {k: z[k] for k in ("frame_index", "snr_db", "doppler_hz", "pilot_density", "channel_type", "metrics")}
-            else:
+            rec = _load_if_same_job(path, b0, b1) if os.path.exists(path) else None
+            if rec is None:
+                if os.path.exists(path):
+                    manifest["regenerated"].append(os.path.basename(path))
                 rec = self._native_range(num_samples, b0, b1, seed, **kwargs)
+                rec["gen_params"] = np.asarray(params_json)
                 while len(pending) >= max(1, int(writers)):                        # bound the chunks held on the host
                     pending.pop(0).result()
                 pending.append(pool.submit(_write, path, rec))
             ct = np.asarray([CHANNEL_NAMES.index(str(c)) for c in rec["channel_type"]], dtype=np.float32)
             m = np.asarray(rec["metrics"], dtype=np.float32)
-            records.append(np.column_stack([np.asarray(rec["frame_index"], dtype=np.float32), ct, rec["doppler_hz"], rec["snr_db"],
-                                            rec["pilot_density"], m[:, 0], m[:, 1], m[:, 2], m[:, 6]]).astype(np.float32))
+            frame_ids.append(np.asarray(rec["frame_index"], dtype=np.int64))
+            records.append(np.column_stack([ct, rec["doppler_hz"], rec["snr_db"], rec["pilot_density"], m[:, 0], m[:, 1], m[:, 2],
+                                            m[:, 6]]).astype(np.float32))
         for fut in pending:
             fut.result()                                                           # re-raises a writer's exception
         pool.shutdown()
-        # the job's single collective: every rank's per-frame (index, type, doppler, snr, density, sum|H|^2, LS / MMSE error
-        # sums, count) records, 36 B per frame (the tensors stay in their rank's shard files)
-        local = np.concatenate(records) if records else np.zeros((0, 9), np.float32)
-        allrec = _sharding.gather_records(local)
-        tot = allrec[:, 8].sum() if len(allrec) else 1.0
-        manifest["summary"] = {"frames_all_ranks": int(len(allrec)),
-                               "mse_ls": float(allrec[:, 6].sum() / tot) if len(allrec) else None,
-                               "mse_mmse": float(allrec[:, 7].sum() / tot) if len(allrec) else None,
-                               "frames_per_channel_type": {n: int((allrec[:, 1] == i).sum()) for i, n in enumerate(CHANNEL_NAMES)}}
+        # the job's single collective: every rank's per-frame (type, doppler, snr, density, sum|H|^2, LS / MMSE error sums,
+        # count) float32 records plus the int64 frame indices, gathered to rank 0 (the tensors stay in their rank's files)
+        local = np.concatenate(records) if records else np.zeros((0, 8), np.float32)
+        local_ids = np.concatenate(frame_ids) if frame_ids else np.zeros(0, np.int64)
+        allrec, allids = _sharding.gather_records(local, local_ids, dst=0)
+        if allrec is not None:
+            tot = allrec[:, 7].sum() if len(allrec) else 1.0
+            manifest["summary"] = {"frames_all_ranks": int(len(allrec)),
+                                   "frame_index_min": int(allids.min()) if len(allids) else None,
+                                   "frame_index_max": int(allids.max()) if len(allids) else None,
+                                   "mse_ls": float(allrec[:, 5].sum() / tot) if len(allrec) else None,
+                                   "mse_mmse": float(allrec[:, 6].sum() / tot) if len(allrec) else None,
+                                   "frames_per_channel_type": {n: int((allrec[:, 0] == i).sum()) for i, n in enumerate(CHANNEL_NAMES)}}
         with open(os.path.join(out_dir, f"{split}_rank{rank:02d}_manifest.json"), "w") as f:
             json.dump(manifest, f, indent=1)
         return manifest

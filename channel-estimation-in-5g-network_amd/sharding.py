@@ -4,7 +4,7 @@ Frames are independent: every random draw of frame i is a pure function of (seed
 contiguous split of [0, total) over the ranks produces exactly the frames a single GPU would
 (reference loop: src/dataset_generator.py:112-125, which is sequential only because it shares one
 global RNG).  There is no collective on the data path; the job ends with ONE gather of the small
-per-frame metadata / metric records.
+per-frame metadata / metric records (36 + 8 bytes per frame) to rank 0.
 """
 from __future__ import annotations
 
@@ -41,27 +41,51 @@ def frame_choices(seed: int, frame_index: np.ndarray, num_options):
     return out
 
 
-def gather_records(local: "np.ndarray", group=None):
-    """The job's single collective: all ranks' per-frame records (float32 [n_local, C]), concatenated in
-    rank order on every rank.  Works on CPU (gloo) and GPU (nccl = RCCL) process groups."""
+def gather_records(local: "np.ndarray", frame_index: "np.ndarray" = None, dst: int = 0, all_ranks: bool = False, group=None):
+    """The job's single collective: every rank's per-frame records (float32 [n_local, C]) and, separately, their GLOBAL
+    frame indices as int64 (float32 is exact only below 2^24 frames), concatenated in rank order.
+
+    Default: a ``gather`` to rank ``dst`` (the north-star's "single gather at the end"); the other ranks get
+    ``(None, None)``.  ``all_ranks=True`` makes it an ``all_gather`` for jobs in which every rank needs the summary.
+    Ragged shard sizes are padded to the largest one.  Works on CPU (gloo) and GPU (nccl = RCCL) process groups; without
+    an initialised group it returns the local arrays."""
     import torch
     import torch.distributed as dist
+    local = np.asarray(local, dtype=np.float32)
+    if local.ndim == 1:
+        local = local[:, None]
+    ids = np.arange(len(local), dtype=np.int64) if frame_index is None else np.asarray(frame_index, dtype=np.int64)
+    if len(ids) != len(local):
+        raise ValueError("frame_index and records differ in length")
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
-        return np.asarray(local)
-    world = dist.get_world_size(group)
+        return local, ids
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
     backend = dist.get_backend(group)
     dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
-    t = torch.as_tensor(np.ascontiguousarray(local), dtype=torch.float32, device=dev)
-    n = torch.tensor([t.shape[0]], dtype=torch.int64, device=dev)
+    n = torch.tensor([local.shape[0]], dtype=torch.int64, device=dev)
     counts = [torch.zeros_like(n) for _ in range(world)]
-    dist.all_gather(counts, n, group=group)
+    dist.all_gather(counts, n, group=group)                           # 8 bytes per rank: the shard sizes
     counts = [int(c.item()) for c in counts]
-    width = t.shape[1] if t.dim() == 2 else 1
-    pad = torch.zeros((max(counts), width), dtype=torch.float32, device=dev)
-    pad[: t.shape[0]] = t.reshape(-1, width)
-    parts = [torch.zeros_like(pad) for _ in range(world)]
-    dist.all_gather(parts, pad, group=group)
-    return torch.cat([p[:c] for p, c in zip(parts, counts)]).cpu().numpy()
+    width, cap = local.shape[1], max(counts)
+    rec = torch.zeros((cap, width), dtype=torch.float32, device=dev)
+    rec[: local.shape[0]] = torch.from_numpy(np.ascontiguousarray(local)).to(dev)
+    idt = torch.zeros(cap, dtype=torch.int64, device=dev)
+    idt[: len(ids)] = torch.from_numpy(np.ascontiguousarray(ids)).to(dev)
+    if all_ranks:
+        rparts = [torch.zeros_like(rec) for _ in range(world)]
+        iparts = [torch.zeros_like(idt) for _ in range(world)]
+        dist.all_gather(rparts, rec, group=group)
+        dist.all_gather(iparts, idt, group=group)
+    else:
+        root = rank == dst
+        rparts = [torch.zeros_like(rec) for _ in range(world)] if root else None
+        iparts = [torch.zeros_like(idt) for _ in range(world)] if root else None
+        dist.gather(rec, rparts, dst=dst, group=group)
+        dist.gather(idt, iparts, dst=dst, group=group)
+        if not root:
+            return None, None
+    return (torch.cat([p[:c] for p, c in zip(rparts, counts)]).cpu().numpy(),
+            torch.cat([p[:c] for p, c in zip(iparts, counts)]).cpu().numpy())
 
 
 def broadcast_from_root(t, src: int = 0, group=None):

@@ -39,12 +39,20 @@ def test_native_dataset_schema_and_sharding_invariance(tmp_path):
     parts = [gen.generate_dataset_native(N, seed=42, rank=r, world=3, pattern_group=32, batch_frames=17) for r in range(3)]
     for k in ("rx_symbols", "H_true", "H_ls", "H_mmse", "pilot_mask", "snr_db", "doppler_hz", "frame_index", "metrics"):
         assert np.array_equal(np.concatenate([p[k] for p in parts]), whole[k]), k
-    # small pattern groups with the plans built in a worker pool: identical frames
-    a = gen.generate_dataset_native(24, seed=5, pattern_group=3)
-    b = gen.generate_dataset_native(24, seed=5, pattern_group=3, plan_workers=4)
-    for k in ("H_ls", "H_mmse", "pilot_mask"):
-        assert np.array_equal(a[k], b[k])
-    assert len({m.tobytes() for m in a["pilot_mask"]}) >= 8          # 8 groups x 2 densities -> many distinct patterns
+    assert np.array_equal(whole["frame_status"], np.zeros(N, np.uint8))
+    # default: a NEW pilot pattern for every frame (src/channel_simulator.py:390-391), drawn and triangulated on the device
+    # from (seed, global frame index) -- hence invariant to batching and sharding
+    a = gen.generate_dataset_native(24, seed=5)
+    b = np.concatenate([gen.generate_dataset_native(24, seed=5, rank=r, world=2, batch_frames=5)["H_ls"] for r in range(2)])
+    assert np.array_equal(a["H_ls"], b)
+    assert len({m.tobytes() for m in a["pilot_mask"]}) == 24
+    for i in (0, 23):
+        P = int(14 * 599 * float(a["pilot_density"][i]))
+        assert np.array_equal(np.flatnonzero(a["pilot_mask"][i].ravel()), PH.native_pilot_pattern(5, i, 14 * 599, P))
+    c = gen.generate_dataset_native(24, seed=5, pattern_group=3)
+    assert 8 <= len({m.tobytes() for m in c["pilot_mask"]}) <= 16     # 8 groups x 2 densities
+    with pytest.raises(MemoryError):
+        gen.generate_dataset_native(10**6, seed=1)                    # 1.1 TB do not fit the host budget: use the streaming writer
     # spot-check one frame against the float64 oracle on the same Philox streams
     i = 37
     mask = whole["pilot_mask"][i].astype(bool)
@@ -93,9 +101,24 @@ def test_streaming_shard_writer_and_exact_resume(tmp_path):
     assert np.array_equal(np.load(victim)["H_true"], before)
     assert all(os.path.getmtime(tmp_path / f) == mtimes[f] for f in files if f != victim.name)
     man = json.load(open(tmp_path / "train_rank01_manifest.json"))
-    assert man["chunks"][1]["first_frame"] == 36 and man["world"] == 2
+    assert man["chunks"][1]["first_frame"] == 36 and man["params"]["world"] == 2 and man["regenerated"] == []
+    # a rerun into the same directory with OTHER parameters must not adopt the old chunks: they are regenerated
+    man2 = gen.generate_dataset_native_to_files(N, str(tmp_path), split="train", seed=8, rank=1, world=2, chunk_frames=11,
+                                                pattern_group=16)
+    assert sorted(man2["regenerated"]) == [f for f in files if "rank01" in f]
+    other = gen.generate_dataset_native(N, seed=8, pattern_group=16)
+    got = np.concatenate([np.load(tmp_path / f)["H_true"] for f in files if "rank01" in f])
+    assert np.array_equal(got, other["H_true"][25:])
+    # ... and a chunk whose frame range does not match (edited / foreign file with the right name) is replaced as well
+    z = dict(np.load(victim)); z["frame_index"] = z["frame_index"] + 1
+    np.savez(victim, **z)
+    man3 = gen.generate_dataset_native_to_files(N, str(tmp_path), split="train", seed=8, rank=1, world=2, chunk_frames=11,
+                                                pattern_group=16)
+    assert man3["regenerated"] == [victim.name]
+    man = man3
     # no process group here: the "gather" is this rank's own 25 records; the summary matches the stored tensors
     assert man["summary"]["frames_all_ranks"] == 25 and sum(man["summary"]["frames_per_channel_type"].values()) == 25
+    whole = other
     sel = whole["frame_index"] >= 25
     err = np.abs(whole["H_true"][sel] - whole["H_ls"][sel]) ** 2
     assert man["summary"]["mse_ls"] == pytest.approx(float(err.mean()), rel=1e-4)

@@ -238,7 +238,34 @@ def test_place_outputs_returns_usable_buffers():
     assert list(only) == ["H_ls"] and rep1["combinations"] == 1
 
 
-def test_many_pilots_fall_back_to_direct_pilot_symbol_stores():
-    """4x4 / 2048-FFT with 12 % pilots (P = 2 014): staging the pilot symbols in LDS would need 171 KB, so the frame kernel
-    writes them straight to global memory instead (155 KB); all outputs still match the oracle."""
+def test_many_pilots_at_the_lds_limit_of_the_frame_kernel():
+    """4x4 / 2048-FFT with 12 % pilots (P = 2 014): LS estimates at the pilots (64 KB) plus a one-rx slab (86 KB) just fit
+    the CU's 160 KB of LDS; all outputs still match the oracle."""
     _check_native(E.Geometry(fft_size=2048, cp_length=144, useful_subcarriers=1200, num_tx=4, num_rx=4), "EVA", 100.0, 10.0, 0.12, B=1)
+
+
+def test_per_frame_status_marks_only_the_bad_frames_and_the_batch_continues():
+    """The reference's dataset loop prints and skips a failed sample and goes on (src/dataset_generator.py:120-125).  The
+    batch path reports per frame: 0 ok, 1 bad descriptor (channel type / pattern slot), 2 estimates requested for a
+    pattern without a plan; the other frames of the batch are produced and equal a clean run."""
+    eng = E.Engine(E.Geometry(useful_subcarriers=72), 0)
+    pil = np.arange(0, 14 * 71, 9)
+    good = eng.pattern_slot(pil, "linear")
+    noplan = eng.pattern_slot(np.arange(0, 14 * 71, 7), None, with_plan=False)
+    B = 12
+    d = E.make_descs("EVA", 70.0, 10.0, good, n=B)
+    clean = eng.run_frames(d, seed=4, outputs=("rx", "H_ls", "frame_status"))
+    assert torch.equal(clean["frame_status"].cpu(), torch.zeros(B, dtype=torch.uint8))
+    bad = d.copy()
+    bad["channel_type"][3] = 7            # unknown profile
+    bad["pattern_slot"][5] = 4000         # slot never set
+    bad["pattern_slot"][8] = noplan       # no interpolation plan, estimates requested
+    out = {k: torch.full_like(v, 9) if k == "frame_status" else torch.zeros_like(v) for k, v in clean.items()}
+    eng.run_frames(bad, seed=4, outputs=("rx", "H_ls", "frame_status"), out=out, check=False)
+    with pytest.raises(N_.ChestError):
+        eng.check_status()                # the global word still says "something failed" ...
+    st = out["frame_status"].cpu().numpy()
+    assert st.tolist() == [0, 0, 0, 1, 0, 1, 0, 0, 2, 0, 0, 0]         # ... and the per-frame bytes say which
+    okf = st == 0
+    assert torch.equal(out["rx"][okf], clean["rx"][okf]) and torch.equal(out["H_ls"][okf], clean["H_ls"][okf])
+    assert float(out["rx"][~okf].abs().max()) == 0.0                   # failed frames leave their outputs untouched

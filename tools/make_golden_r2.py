@@ -10,7 +10,7 @@ tools/make_golden.py stay untouched):
                                 statistics of H / rx / H_ls, the full tensors of three frames, and the next draw of the
                                 global stream after the loop.  The oracle replay (legacy draws from the same seed) is
                                 asserted to match every frame to <= 1e-12 before anything is written.
-  full_2x2_etu_fullcov.npz      one full-size frame (P = 838) of MMSEEstimator(channel_covariance=R,
+  fullcov_full_2x2_etu.npz      one full-size frame (P = 838) of MMSEEstimator(channel_covariance=R,
                                 estimate_statistics=False).estimate (src/baseline_estimators.py:181-190) on the reference:
                                 pins config 5's size class by the reference itself, not only by the oracle.  The
                                 covariance is the harness formula (bench.fullcov_covariance); only its checksum is stored.
@@ -116,9 +116,9 @@ def fullcov_full(cs, be, out_dir, seed=5150):
         H_fullcov=H_fc[:, :, 0, :].astype(np.complex64), mse_fullcov=m["mse"], nmse_db_fullcov=m["nmse_db"],
         cov_checksum=np.array([np.sum(cov), np.sum(np.abs(cov) ** 2)]),
     )
-    path = os.path.join(out_dir, "full_2x2_etu_fullcov.npz")
+    path = os.path.join(out_dir, "fullcov_full_2x2_etu.npz")
     np.savez_compressed(path, **payload)
-    print(f"full_2x2_etu_fullcov    ok  oracle vs reference {e:.2e}  {os.path.getsize(path) / 1024:.0f} KiB")
+    print(f"fullcov_full_2x2_etu    ok  oracle vs reference {e:.2e}  {os.path.getsize(path) / 1024:.0f} KiB")
 
 
 def main():
