@@ -118,7 +118,7 @@ class MMSEEstimator:
         self.channel_covariance = channel_covariance
         self.noise_variance = noise_variance
         self.estimate_statistics = estimate_statistics
-        self._W_cache = None          # (snr_db, id(cov)) -> W on device
+        self._W_cache = None          # ((snr_db, content hash of the covariance, engine), W on the device)
 
     def estimate_covariance(self, h_ls: np.ndarray) -> np.ndarray:
         """np.cov over the flattened leading dimensions (:137-153); host-side helper nobody calls on the hot path."""
@@ -129,9 +129,27 @@ class MMSEEstimator:
         return self.estimate_statistics or self.channel_covariance is None
 
     def _full_W(self, eng, snr_db):
-        key = (float(snr_db), id(self.channel_covariance), eng)
+        """W = R (R + sigma^2 I)^-1 on the device (float64), cached on the CONTENT of the covariance (a covariance modified
+        in place, or a new array at a recycled id, must not reuse a stale filter).  The device inverts without pivoting, which
+        is exact-arithmetic-safe for the Hermitian positive semi-definite matrices a covariance is; anything else is
+        rejected.  A singular R + sigma^2 I (non-finite W) is retried with the reference's +1e-6 I loading (:191-194) and
+        raises LinAlgError if that fails too."""
+        import hashlib
+        cov = self.channel_covariance
+        cov = np.ascontiguousarray(cov.cpu().numpy() if _is_tensor(cov) else cov, dtype=np.complex128)
+        if cov.ndim != 2 or cov.shape[0] != cov.shape[1]:
+            raise ValueError("channel_covariance must be a square P x P matrix")
+        key = (float(snr_db), hashlib.blake2b(cov.tobytes(), digest_size=16).digest(), cov.shape[0], id(eng))
         if self._W_cache is None or self._W_cache[0] != key:
-            self._W_cache = (key, eng.mmse_full_prepare(self.channel_covariance, snr_db))
+            scale = max(float(np.max(np.abs(cov))), 1e-300)
+            if not np.allclose(cov, cov.conj().T, rtol=0.0, atol=1e-10 * scale):
+                raise ValueError("channel_covariance must be Hermitian (the device path inverts R + sigma^2 I without pivoting)")
+            W = eng.mmse_full_prepare(cov, snr_db)
+            if not bool(torch.isfinite(torch.view_as_real(W)).all()):
+                W = eng.mmse_full_prepare(cov + 1e-6 * np.eye(cov.shape[0]), snr_db)
+                if not bool(torch.isfinite(torch.view_as_real(W)).all()):
+                    raise np.linalg.LinAlgError("Singular matrix")
+            self._W_cache = (key, W)
         return self._W_cache[1]
 
     def estimate_at_pilots(self, rx_symbols, tx_pilots, pilot_mask, snr_db: float = 10):

@@ -41,7 +41,7 @@ def _check_native(geom, ctype, fd, snr, density, B=2, seed=5, off=11, method="li
         assert np.array_equal(out["pilot_mask"][b].cpu().numpy().astype(bool), o["pilot_mask"])
         m = out["metrics"][b].cpu().numpy().astype(np.float64)
         ref = O.evaluate_estimator(o["channel"], ls)
-        assert m[1] / m[6] == pytest.approx(ref["mse"], rel=5e-5)
+        assert m[1] / m[6] == pytest.approx(ref["mse"], rel=1e-5)
     return eng
 
 

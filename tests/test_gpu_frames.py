@@ -59,9 +59,9 @@ def test_frame_pipeline_matches_reference_golden(name):
     n = m[6]
     mse_ls = m[1] / n
     nmse_ls = mse_ls / (m[0] / n + 1e-12)
-    assert mse_ls == pytest.approx(float(g["mse_ls"]), rel=2e-5)
+    assert mse_ls == pytest.approx(float(g["mse_ls"]), rel=1e-5)
     assert 10 * np.log10(nmse_ls + 1e-12) == pytest.approx(float(g["nmse_db_ls"]), abs=1e-4)
-    assert m[2] / n == pytest.approx(float(g["mse_mmse"]), rel=2e-5)
+    assert m[2] / n == pytest.approx(float(g["mse_mmse"]), rel=1e-5)
 
 
 def test_nearest_plan_matches_reference():

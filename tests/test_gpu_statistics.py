@@ -129,3 +129,30 @@ def test_snr_sweep_matches_reference_curve():
         assert power == pytest.approx(0.5, rel=0.02)               # E|H|^2 of ETU (all nine paths survive) = 0.5
         assert power == pytest.approx(row["power"], rel=0.15)        # the reference's 30-frame mean fluctuates by ~4 % rms
         assert mse_mm <= mse_ls
+
+
+def test_config3_4x4_snr_sweep_at_full_size_matches_the_reference_curve():
+    """BASELINE config 3 as specified: 4x4, ETU 370.4 Hz (200 km/h @ 2 GHz), SNR -5..30 dB in 5-dB steps, 10 % pilots,
+    6 250 frames per SNR point = 50 000 frames, a NEW device-drawn pilot pattern every 25 frames.  Frame-averaged LS / MMSE MSE
+    per SNR against the curve of the REAL reference at 4x4 (tools/make_snr_sweep_golden_4x4.py: the loop of
+    test_phase2_snr_sweep.py:18-64 of the reference, 50 frames per SNR).  Different random streams, so the comparison is
+    statistical: 4 standard errors of the reference mean + 2 %."""
+    import json
+    import os
+    from conftest import GOLDEN
+    ref = json.load(open(os.path.join(GOLDEN, "snr_sweep_ref_4x4.json")))
+    assert ref["mimo"] == "4x4" and len(ref["snr"]) == 8
+    geom = E.Geometry(num_tx=4, num_rx=4)
+    eng = E.Engine(geom, 0)
+    G = geom.grid
+    F, group = 6250, 25
+    slots = eng.build_patterns(0, [int(G * 0.10)] * (F // group), seed=77, pattern_ids=np.arange(F // group, dtype=np.uint64), method="linear")
+    for row in ref["snr"]:
+        d = E.make_descs("ETU", ref["doppler_hz"], float(row["snr_db"]), slots[np.arange(F) // group], n=F)
+        m = eng.run_frames(d, seed=4242, frame_offset=int(row["snr_db"] + 100) * 10**6, outputs=("metrics",))["metrics"].double()
+        mse_ls, mse_mm, power = float((m[:, 1] / m[:, 6]).mean()), float((m[:, 2] / m[:, 6]).mean()), float((m[:, 0] / m[:, 6]).mean())
+        n = ref["frames_per_snr"] ** 0.5
+        assert abs(mse_ls - row["mse_ls"]) < 4 * row["mse_ls_std"] / n + 0.02 * row["mse_ls"], (row["snr_db"], mse_ls, row["mse_ls"])
+        assert abs(mse_mm - row["mse_mmse"]) < 4 * row["mse_mmse_std"] / n + 0.02 * row["mse_mmse"], (row["snr_db"], mse_mm, row["mse_mmse"])
+        assert power == pytest.approx(0.5, rel=0.01) and mse_mm <= mse_ls
+    eng.close()
