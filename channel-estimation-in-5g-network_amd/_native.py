@@ -59,7 +59,9 @@ SIGNATURES = {
     "chest_get_tap_table": (_i32, [_vp, _i32, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(C.c_double)]),
     "chest_pattern_set": (_i32, [_vp, _i32, _vp, _i32, _vp, _vp]),
     "chest_pattern_set_triangulation": (_i32, [_vp, _i32, _vp, _i32, _vp, _i32]),
-    "chest_patterns_build": (_i32, [_vp, _vp, _i32, _i32, _vp, _vp, _i32, _u64, _vp, _i32, _vp, _vp]),
+    "chest_patterns_build": (_i32, [_vp, _vp, _i32, _i32, _vp, _vp, _i32, _u64, _vp, _i32, _vp, _vp, _vp]),
+    "chest_cubic_workspace_bytes": (_i64, [_vp, _i32]),
+    "chest_cubic_operator": (_i32, [_vp, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _i64]),
     "chest_pattern_get_pilots": (_i32, [_vp, _i32, _vp]),
     "chest_pattern_get_plan": (_i32, [_vp, _i32, _vp, _vp]),
     "chest_pattern_num_pilots": (_i32, [_vp, _i32]),

@@ -3,68 +3,36 @@
 //
 // prepare: W = R (R + s2 I)^-1 = I - s2 (R + s2 I)^-1.  The system is Hermitian positive definite and
 //          fp32-ill-conditioned at high SNR (cond ~ 3.5e5), so the inverse is formed in float64
-//          on the device by in-place Gauss-Jordan (no pivoting needed for HPD), then rounded once to c64.
-//          It runs once per (pilot pattern, sigma^2).
+//          on the device by a BLOCKED in-place Gauss-Jordan sweep (64-wide pivot blocks, no pivoting needed for HPD),
+//          then rounded once to c64.  It runs once per (pilot pattern, sigma^2).
 // apply  : gather h_ls = y/(x+1e-12) for all B*R*T grids, complex GEMM W[P,P] x h_ls[P,M] on the exact-f32
 //          MFMA pipe (v_mfma_f32_32x32x2_f32; 4 real MFMAs per complex k-pair), then the usual plan-driven
 //          interpolation.  This is the only MFMA-shaped work on the hot path.
-#include <stdlib.h>
-
-#include <stdio.h>
 #include "chest_device.h"
 #include "chest_internal.h"
+#include "gj_blocked.h"
 
 namespace chest {
 
-struct cdd { double x, y; };
-__device__ __forceinline__ cdd zmul(cdd a, cdd b) { return {a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
 
-__global__ void __launch_bounds__(256) gj_init_kernel(int P, const cdd* __restrict__ cov, double s2, cdd* __restrict__ A) {
-    const size_t n = (size_t)P * P;
+// ---- prepare: blocked in-place Gauss-Jordan inversion in float64 (gj_blocked.h) ------------------------------------------
+__global__ void __launch_bounds__(256) gjb_init_kernel(int P, int Ppad, const cdd* __restrict__ cov, double s2, cdd* __restrict__ A) {
+    const size_t n = (size_t)Ppad * Ppad;
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
-        cdd v = cov[e];
-        if (e / P == e % P) v.x += s2;
+        const int i = (int)(e / Ppad), j = (int)(e % Ppad);
+        cdd v{0.0, 0.0};
+        if (i < P && j < P) { v = cov[(size_t)i * P + j]; if (i == j) v.x += s2; }
+        else if (i == j) v.x = 1.0;
         A[e] = v;
     }
 }
 
-// pivot step part 1: save the scaled pivot row and the pivot column
-__global__ void __launch_bounds__(256) gj_extract_kernel(int P, int p, const cdd* __restrict__ A, cdd* __restrict__ rowbuf,
-                                                         cdd* __restrict__ colbuf) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= P) return;
-    const cdd piv = A[(size_t)p * P + p];
-    const double d2 = piv.x * piv.x + piv.y * piv.y;
-    const cdd inv = {piv.x / d2, -piv.y / d2};
-    rowbuf[j] = (j == p) ? inv : zmul(A[(size_t)p * P + j], inv);
-    colbuf[j] = A[(size_t)j * P + p];
-}
-
-// pivot step part 2: rank-1 update of the whole matrix (in-place inverse bookkeeping)
-__global__ void __launch_bounds__(256) gj_update_kernel(int P, int p, cdd* __restrict__ A, const cdd* __restrict__ rowbuf,
-                                                        const cdd* __restrict__ colbuf) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    const int i = blockIdx.y;
-    if (j >= P) return;
-    const cdd rj = rowbuf[j];
-    cdd v;
-    if (i == p) {
-        v = rj;
-    } else {
-        const cdd ci = colbuf[i];
-        const cdd q = zmul(ci, rj);
-        if (j == p) v = {-q.x, -q.y};
-        else { v = A[(size_t)i * P + j]; v.x -= q.x; v.y -= q.y; }
-    }
-    A[(size_t)i * P + j] = v;
-}
-
-__global__ void __launch_bounds__(256) gj_finish_kernel(int P, const cdd* __restrict__ Ainv, double s2, float2* __restrict__ W) {
+__global__ void __launch_bounds__(256) gjb_finish_kernel(int P, int Ppad, const cdd* __restrict__ Ainv, double s2, float2* __restrict__ W) {
     const size_t n = (size_t)P * P;
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
-        const cdd a = Ainv[e];
-        const double diag = (e / P == e % P) ? 1.0 : 0.0;
-        W[e] = make_float2((float)(diag - s2 * a.x), (float)(-s2 * a.y));
+        const int i = (int)(e / P), j = (int)(e % P);
+        const cdd a = Ainv[(size_t)i * Ppad + j];
+        W[e] = make_float2((float)((i == j ? 1.0 : 0.0) - s2 * a.x), (float)(-s2 * a.y));
     }
 }
 
@@ -93,208 +61,15 @@ gather_ls_kernel(int S, int R, int T, int nsc, int P, int Ppad, int M, const int
 }
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
-constexpr int GB_M = 64, GB_N = 64, GB_K = 16, GB_LD = GB_K + 1;   // +1 float2 pad: conflict-free ds_read_b64
-
-// C[m][i] = sum_k W[i][k] * Hin[m][k]   (complex, K = Ppad).  Block 256 threads = 4 waves, each a
-// 32x32 tile of the 64(i) x 64(m) block tile; LDS tiles are [row][k] float2 with one pad element.
-__global__ void __launch_bounds__(256)
-cgemm_w_kernel(int P, int Ppad, int M, const float2* __restrict__ W, const float2* __restrict__ Hin,
-               float2* __restrict__ Hout) {
-    __shared__ float2 As[GB_M * GB_LD];
-    __shared__ float2 Bs[GB_N * GB_LD];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int i0 = blockIdx.x * GB_M, m0 = blockIdx.y * GB_N;
-    const int wi = (wave & 1) * 32, wm = (wave >> 1) * 32;
-    f32x16 cre = {0}, cim = {0};
-    const int lrow = tid >> 2;                 // 0..63 : tile row loaded by this thread
-    const int lk = (tid & 3) * 4;              // 0,4,8,12 : first of 4 complex k it loads
-    for (int k0 = 0; k0 < Ppad; k0 += GB_K) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int k = k0 + lk + q;
-            float2 a = make_float2(0.f, 0.f), bv = make_float2(0.f, 0.f);
-            if (i0 + lrow < P && k < P) a = W[(size_t)(i0 + lrow) * P + k];
-            if (m0 + lrow < M && k < Ppad) bv = Hin[(size_t)(m0 + lrow) * Ppad + k];
-            As[lrow * GB_LD + lk + q] = a;
-            Bs[lrow * GB_LD + lk + q] = bv;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int kk = 0; kk < GB_K; kk += 2) {
-            // 32x32x2 operand map: lane l holds A[i = l&31][k = l>>5], B[k = l>>5][j = l&31]
-            const float2 a = As[(wi + (lane & 31)) * GB_LD + kk + (lane >> 5)];
-            const float2 bb = Bs[(wm + (lane & 31)) * GB_LD + kk + (lane >> 5)];
-            cre = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bb.x, cre, 0, 0, 0);
-            cre = __builtin_amdgcn_mfma_f32_32x32x2f32(-a.y, bb.y, cre, 0, 0, 0);
-            cim = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bb.y, cim, 0, 0, 0);
-            cim = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bb.x, cim, 0, 0, 0);
-        }
-        __syncthreads();
-    }
-    // C/D map: col j = lane&31 (the m index), row i = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
-    const int m = m0 + wm + (lane & 31);
-    if (m < M) {
-#pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-            const int i = i0 + wi + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
-            if (i < P) Hout[(size_t)m * Ppad + i] = make_float2(cre[reg], cim[reg]);
-        }
-    }
-}
-
-// Second-generation tile: 128 x 128 block, 4 waves x (2 x 2) 32x32 MFMA tiles, i.e. 16 MFMAs per four ds_read_b64 (the
-// 64 x 64 version issues 4 per two).  Rows of the MFMA tile = grids m (registers), columns = pilot index i (lanes), so
-// every C/D register is stored as a 256-B run of Hout[m][i0..i0+31].
-constexpr int T2_M = 128, T2_N = 128, T2_K = 16, T2_LD = T2_K + 1;
-
-__global__ void __launch_bounds__(256)
-cgemm_w_kernel_v2(int P, int Ppad, int M, const float2* __restrict__ W, const float2* __restrict__ Hin,
-                  float2* __restrict__ Hout) {
-    __shared__ float2 Hs[T2_M * T2_LD];        // [m][k]  A operand
-    __shared__ float2 Ws[T2_N * T2_LD];        // [i][k]  B operand
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int i0 = blockIdx.x * T2_N, m0 = blockIdx.y * T2_M;
-    const int wm = (wave & 1) * 64, wi = (wave >> 1) * 64;
-    f32x16 cre[2][2], cim[2][2];
-#pragma unroll
-    for (int x = 0; x < 2; ++x)
-#pragma unroll
-        for (int y = 0; y < 2; ++y)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) { cre[x][y][e] = 0.f; cim[x][y][e] = 0.f; }
-    const int lrow = tid >> 1, lk = (tid & 1) * 8;
-    // register-staged software pipeline: the global loads of tile t+1 are issued before the MFMA block of tile t and
-    // written to LDS after it, so their latency hides under ~8k cycles of matrix work per wave
-    float2 ph[8], pw[8];
-    auto fetch = [&](int k0) {
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int k = k0 + lk + q;
-            ph[q] = (m0 + lrow < M && k < Ppad) ? Hin[(size_t)(m0 + lrow) * Ppad + k] : make_float2(0.f, 0.f);
-            pw[q] = (i0 + lrow < P && k < P) ? W[(size_t)(i0 + lrow) * P + k] : make_float2(0.f, 0.f);
-        }
-    };
-    fetch(0);
-    for (int k0 = 0; k0 < Ppad; k0 += T2_K) {
-#pragma unroll
-        for (int q = 0; q < 8; ++q) { Hs[lrow * T2_LD + lk + q] = ph[q]; Ws[lrow * T2_LD + lk + q] = pw[q]; }
-        __syncthreads();
-        if (k0 + T2_K < Ppad) fetch(k0 + T2_K);
-#pragma unroll
-        for (int kk = 0; kk < T2_K; kk += 2) {
-            float2 a[2], b[2];
-#pragma unroll
-            for (int x = 0; x < 2; ++x) a[x] = Hs[(wm + 32 * x + (lane & 31)) * T2_LD + kk + (lane >> 5)];
-#pragma unroll
-            for (int y = 0; y < 2; ++y) b[y] = Ws[(wi + 32 * y + (lane & 31)) * T2_LD + kk + (lane >> 5)];
-#pragma unroll
-            for (int x = 0; x < 2; ++x)
-#pragma unroll
-                for (int y = 0; y < 2; ++y) {
-                    cre[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[x].x, b[y].x, cre[x][y], 0, 0, 0);
-                    cre[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(-a[x].y, b[y].y, cre[x][y], 0, 0, 0);
-                    cim[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[x].x, b[y].y, cim[x][y], 0, 0, 0);
-                    cim[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[x].y, b[y].x, cim[x][y], 0, 0, 0);
-                }
-        }
-        __syncthreads();
-    }
-#pragma unroll
-    for (int x = 0; x < 2; ++x)
-#pragma unroll
-        for (int y = 0; y < 2; ++y) {
-            const int i = i0 + wi + 32 * y + (lane & 31);
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                const int m = m0 + wm + 32 * x + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
-                if (m < M && i < P) Hout[(size_t)m * Ppad + i] = make_float2(cre[x][y][reg], cim[x][y][reg]);
-            }
-        }
-}
-
-// Third generation (default): same 128 x 128 block tile and 2 x 2 MFMA tiles per wave, but
-//   * both operands come from PACKED scratch copies -- rows padded to the tile, K padded to 16, zero filled -- so every
-//     thread fetches its 8 k-values of a row with four unconditional 16-B loads (v2: sixteen 8-B loads, each behind its own
-//     bounds branch: a 165-instruction stretch without a single MFMA per k-tile);
-//   * the LDS tiles are double buffered: the registers of tile t+1 are written to the other buffer right after the MFMA
-//     block of tile t, one barrier per k-tile instead of two.
+// 128 x 128 block tile, 4 waves x (2 x 2) 32x32 MFMA tiles (16 MFMAs per four ds_read_b64).  Rows of the MFMA tile = grids m
+// (registers), columns = pilot index i (lanes), so every C/D register is stored as a 256-B run of Hout[m][i0..i0+31].
+// Both operands come from PACKED scratch copies -- rows padded to the tile, K padded to 16, zero filled -- so every thread
+// fetches its 8 k-values of a row with four unconditional 16-B loads; the LDS tiles ([row][k], one pad element: conflict-
+// free ds_read_b64) are double buffered: the registers of tile t+1 are written to the other buffer right after the MFMA
+// block of tile t, one barrier per k-tile.
+constexpr int T2_M = 128, T2_N = 128, T2_K = 16;
 constexpr int T3_LD = T2_K + 1;
 constexpr size_t T3_LDS_BYTES = (size_t)2 * 2 * T2_M * T3_LD * sizeof(float2);      // 2 buffers x (A, B) = 69 632 B
-
-__global__ void __launch_bounds__(256)
-cgemm_w_kernel_v3(int P, int Kpad, int M, int ldo, const float2* __restrict__ Wp, const float2* __restrict__ Hin,
-                  float2* __restrict__ Hout) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    float2* const lds = (float2*)lds_raw;          // [buf][A | B][128][T3_LD]
-    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-    const int i0 = blockIdx.x * T2_N, m0 = blockIdx.y * T2_M;
-    const int wm = (wave & 1) * 64, wi = (wave >> 1) * 64;
-    f32x16 cre[2][2], cim[2][2];
-#pragma unroll
-    for (int x = 0; x < 2; ++x)
-#pragma unroll
-        for (int y = 0; y < 2; ++y)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) { cre[x][y][e] = 0.f; cim[x][y][e] = 0.f; }
-    const int lrow = tid >> 1, lk = (tid & 1) * 8;
-    const float4* gh = (const float4*)(Hin + (size_t)(m0 + lrow) * Kpad + lk);      // 16-B aligned: Kpad % 16 == 0
-    const float4* gw = (const float4*)(Wp + (size_t)(i0 + lrow) * Kpad + lk);
-    float4 ph[4], pw[4];
-    auto fetch = [&](int k0) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { ph[q] = gh[(k0 >> 1) + q]; pw[q] = gw[(k0 >> 1) + q]; }
-    };
-    auto stage = [&](int buf) {
-        float2* Hs = lds + (size_t)buf * 2 * T2_M * T3_LD;
-        float2* Ws = Hs + T2_M * T3_LD;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            Hs[lrow * T3_LD + lk + 2 * q] = make_float2(ph[q].x, ph[q].y);
-            Hs[lrow * T3_LD + lk + 2 * q + 1] = make_float2(ph[q].z, ph[q].w);
-            Ws[lrow * T3_LD + lk + 2 * q] = make_float2(pw[q].x, pw[q].y);
-            Ws[lrow * T3_LD + lk + 2 * q + 1] = make_float2(pw[q].z, pw[q].w);
-        }
-    };
-    fetch(0);
-    stage(0);
-    __syncthreads();
-    const int nk = Kpad / T2_K;
-    for (int t = 0; t < nk; ++t) {
-        if (t + 1 < nk) fetch((t + 1) * T2_K);
-        const float2* Hs = lds + (size_t)(t & 1) * 2 * T2_M * T3_LD;
-        const float2* Ws = Hs + T2_M * T3_LD;
-#pragma unroll
-        for (int kk = 0; kk < T2_K; kk += 2) {
-            float2 a[2], b[2];
-#pragma unroll
-            for (int x = 0; x < 2; ++x) a[x] = Hs[(wm + 32 * x + (lane & 31)) * T3_LD + kk + (lane >> 5)];
-#pragma unroll
-            for (int y = 0; y < 2; ++y) b[y] = Ws[(wi + 32 * y + (lane & 31)) * T3_LD + kk + (lane >> 5)];
-#pragma unroll
-            for (int x = 0; x < 2; ++x)
-#pragma unroll
-                for (int y = 0; y < 2; ++y) {
-                    cre[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[x].x, b[y].x, cre[x][y], 0, 0, 0);
-                    cre[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(-a[x].y, b[y].y, cre[x][y], 0, 0, 0);
-                    cim[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[x].x, b[y].y, cim[x][y], 0, 0, 0);
-                    cim[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[x].y, b[y].x, cim[x][y], 0, 0, 0);
-                }
-        }
-        if (t + 1 < nk) stage((t + 1) & 1);
-        __syncthreads();
-    }
-#pragma unroll
-    for (int x = 0; x < 2; ++x)
-#pragma unroll
-        for (int y = 0; y < 2; ++y) {
-            const int i = i0 + wi + 32 * y + (lane & 31);
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                const int m = m0 + wm + 32 * x + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
-                if (m < M && i < P) Hout[(size_t)m * ldo + i] = make_float2(cre[x][y][reg], cim[x][y][reg]);
-            }
-        }
-}
 
 // Three-multiplication complex product ("3M"): (ar + j ai)(br + j bi) = (ar br - ai bi) + j((ar + ai)(br + bi) - ar br - ai bi),
 // i.e. three real MFMAs per complex k-pair instead of four (-25 % matrix work) for three accumulator sets instead of two
@@ -419,59 +194,16 @@ pack_h_kernel(int M, int P, int stride, int Ppad, const float2* __restrict__ h, 
     for (int i = threadIdx.x; i < Ppad; i += blockDim.x) hp[(size_t)m * Ppad + i] = (m < M && i < P) ? h[(size_t)m * stride + i] : make_float2(0.f, 0.f);
 }
 
-// Dense interpolation operator (Clough-Tocher 'cubic', interp_plan.cubic_operator): H[m][g] = sum_p A[g][p] h[m][p],
-// A real [G][P], h complex [M][Ppad].  Rows of the MFMA tile = grids m, columns = resource elements g, so that the
-// 32 lanes of a C/D register hold consecutive subcarriers of one grid row (coalesced 256-B stores into [B][S][R][T][nsc]).
-__global__ void __launch_bounds__(256)
-dense_interp_kernel(int S, int R, int T, int nsc, int P, int Ppad, int M, const float* __restrict__ A,
-                    const float2* __restrict__ h, float2* __restrict__ H_est) {
-    __shared__ float2 Hs[GB_M * GB_LD];        // [m][k]
-    __shared__ float As[GB_N * GB_LD];         // [g][k]
-    const int G = S * nsc;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int m0 = blockIdx.y * GB_M, g0 = blockIdx.x * GB_N;
-    const int wm = (wave & 1) * 32, wg = (wave >> 1) * 32;
-    f32x16 cre = {0}, cim = {0};
-    const int lrow = tid >> 2, lk = (tid & 3) * 4;
-    for (int k0 = 0; k0 < P; k0 += GB_K) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int k = k0 + lk + q;
-            Hs[lrow * GB_LD + lk + q] = (m0 + lrow < M && k < Ppad) ? h[(size_t)(m0 + lrow) * Ppad + k] : make_float2(0.f, 0.f);
-            As[lrow * GB_LD + lk + q] = (g0 + lrow < G && k < P) ? A[(size_t)(g0 + lrow) * P + k] : 0.f;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int kk = 0; kk < GB_K; kk += 2) {
-            const float2 hv = Hs[(wm + (lane & 31)) * GB_LD + kk + (lane >> 5)];      // A operand: rows m
-            const float av = As[(wg + (lane & 31)) * GB_LD + kk + (lane >> 5)];       // B operand: columns g
-            cre = __builtin_amdgcn_mfma_f32_32x32x2f32(hv.x, av, cre, 0, 0, 0);
-            cim = __builtin_amdgcn_mfma_f32_32x32x2f32(hv.y, av, cim, 0, 0, 0);
-        }
-        __syncthreads();
-    }
-    const int g = g0 + wg + (lane & 31);
-    if (g < G) {
-        const int s = g / nsc, k = g - s * nsc;
-#pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-            const int m = m0 + wm + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
-            if (m < M) {
-                const int t = m % T, r = (m / T) % R, b = m / (T * R);
-                H_est[(((size_t)b * S + s) * R + r) * T * nsc + (size_t)t * nsc + k] = make_float2(cre[reg], cim[reg]);
-            }
-        }
-    }
-}
-
-// Second generation of the dense ('cubic') interpolation GEMM, built like cgemm_w_kernel_v3: 128 (grids m) x 128
-// (resource elements g) block tile, 2 x 2 MFMA tiles per wave, operands from tile-padded scratch copies through 16-B loads,
-// double-buffered LDS, one barrier per k-tile.  A is real: two MFMAs per k-pair and sub-tile.
+// Dense interpolation operator (Clough-Tocher 'cubic'): H[m][g] = sum_p A[g][p] h[m][p], A real [G][P], h complex [M][Ppad].
+// Rows of the MFMA tile = grids m, columns = resource elements g, so that the 32 lanes of a C/D register hold consecutive
+// subcarriers of one grid row (coalesced 256-B stores into [B][S][R][T][nsc]).  Built like cgemm_w_kernel_3m: 128 (grids m)
+// x 128 (resource elements g) block tile, 2 x 2 MFMA tiles per wave, operands from tile-padded scratch copies through 16-B
+// loads, double-buffered LDS, one barrier per k-tile.  A is real: two MFMAs per k-pair and sub-tile.
 constexpr int D2_LDH = T2_K + 1, D2_LDA = T2_K + 1;
 constexpr size_t D2_LDS_BYTES = (size_t)2 * (T2_M * D2_LDH * sizeof(float2) + T2_N * D2_LDA * sizeof(float));   // 52 224 B
 
 __global__ void __launch_bounds__(256, 2)
-dense_interp_kernel_v2(int S, int R, int T, int nsc, int Kpad, int M, const float* __restrict__ Ap,
+dense_interp_kernel(int S, int R, int T, int nsc, int Kpad, int M, const float* __restrict__ Ap,
                        const float2* __restrict__ Hin, float2* __restrict__ H_est) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     constexpr size_t BUF = T2_M * D2_LDH * sizeof(float2) + T2_N * D2_LDA * sizeof(float);
@@ -573,7 +305,9 @@ extern "C" {
 
 int64_t chest_mmse_full_workspace_bytes(int32_t P) {
     if (P <= 0) return 0;
-    return (int64_t)sizeof(double) * 2 * ((int64_t)P * P + 2 * (int64_t)P);
+    const int64_t Ppad = ((int64_t)P + GJB - 1) / GJB * GJB;
+    // A [Ppad][Ppad] | Rp [64][Ppad] | Cp [Ppad / 64][64][64] | Dinv [64][64], complex float64
+    return (int64_t)sizeof(double) * 2 * (Ppad * Ppad + 2 * GJB * Ppad + GJB * GJB);
 }
 
 int chest_mmse_full_prepare(chest_ctx* ctx, void* stream, int32_t P, const double* cov, float snr_db, float* W,
@@ -587,17 +321,14 @@ int chest_mmse_full_prepare(chest_ctx* ctx, void* stream, int32_t P, const doubl
     CHEST_GUARD(ctx);
     hipStream_t st = (hipStream_t)stream;
     const double s2 = 1.0 / pow(10.0, (double)snr_db / 10.0);              // (:174-175)
+    const int Ppad = (P + GJB - 1) / GJB * GJB;
     cdd* A = (cdd*)workspace;
-    cdd* rowbuf = A + (size_t)P * P;
-    cdd* colbuf = rowbuf + P;
-    const unsigned nb = (unsigned)(((size_t)P * P + 255) / 256 > 4096 ? 4096 : ((size_t)P * P + 255) / 256);
-    hipLaunchKernelGGL(gj_init_kernel, dim3(nb), dim3(256), 0, st, P, (const cdd*)cov, s2, A);
-    const unsigned bx = (unsigned)((P + 255) / 256);
-    for (int p = 0; p < P; ++p) {
-        hipLaunchKernelGGL(gj_extract_kernel, dim3(bx), dim3(256), 0, st, P, p, A, rowbuf, colbuf);
-        hipLaunchKernelGGL(gj_update_kernel, dim3(bx, (unsigned)P), dim3(256), 0, st, P, p, A, rowbuf, colbuf);
-    }
-    hipLaunchKernelGGL(gj_finish_kernel, dim3(nb), dim3(256), 0, st, P, A, s2, (float2*)W);
+    const size_t n = (size_t)Ppad * Ppad;
+    const unsigned nb = (unsigned)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
+    hipLaunchKernelGGL(gjb_init_kernel, dim3(nb), dim3(256), 0, st, P, Ppad, (const cdd*)cov, s2, A);
+    const int rc = launch_gj_inverse<cdd>(ctx, st, Ppad, A, A + n, LDS_GJ_PANEL, LDS_GJ_UPDATE);
+    if (rc != CHEST_OK) return rc;
+    hipLaunchKernelGGL(gjb_finish_kernel, dim3(nb), dim3(256), 0, st, P, Ppad, A, s2, (float2*)W);
     CHEST_HIP(hipGetLastError());
     return CHEST_OK;
 }
@@ -632,25 +363,10 @@ int chest_mmse_full_apply(chest_ctx* ctx, void* stream, int32_t B, const float* 
     float2* w_packed = h_out + (size_t)M * Ppad;
     hipLaunchKernelGGL(gather_ls_kernel, dim3(Mpad), dim3(256), 0, st, f.S, f.R, f.T, f.nsc, P, Ppad, M, pd.pilot_idx,
                        (const float2*)rx4d, (const float2*)tx_pilots, pilot_stride, h_in);
-    const char* gv = getenv("CHEST_GEMM");   // A/B switch: "1" = first 64x64 tile, "2" = 128x128 with register prefetch
-    if (gv && gv[0] == '1')
-        hipLaunchKernelGGL(cgemm_w_kernel, dim3((P + GB_M - 1) / GB_M, (M + GB_N - 1) / GB_N), dim3(256), 0, st, P, Ppad, M,
-                           (const float2*)W, h_in, h_out);
-    else if (gv && gv[0] == '2')
-        hipLaunchKernelGGL(cgemm_w_kernel_v2, dim3((P + T2_N - 1) / T2_N, (M + T2_M - 1) / T2_M), dim3(256), 0, st, P, Ppad, M,
-                           (const float2*)W, h_in, h_out);
-    else {
-        hipLaunchKernelGGL(pack_w_kernel, dim3(Npad), dim3(256), 0, st, P, Ppad, (const float2*)W, w_packed);
-        if (gv && gv[0] == '3') {         // four real MFMAs per complex k-pair
-            CHEST_LDS_OPT_IN(ctx, LDS_GEMM, cgemm_w_kernel_v3, T3_LDS_BYTES);
-            hipLaunchKernelGGL(cgemm_w_kernel_v3, dim3(Npad / T2_N, Mpad / T2_M), dim3(256), T3_LDS_BYTES, st, P, Ppad, M, Ppad,
-                               (const float2*)w_packed, h_in, h_out);
-        } else {                          // default: three
-            CHEST_LDS_OPT_IN(ctx, LDS_GEMM3M, cgemm_w_kernel_3m, T3_LDS_BYTES);
-            hipLaunchKernelGGL(cgemm_w_kernel_3m, dim3(Npad / T2_N, Mpad / T2_M), dim3(256), T3_LDS_BYTES, st, P, Ppad, M, Ppad,
-                               (const float2*)w_packed, h_in, h_out);
-        }
-    }
+    hipLaunchKernelGGL(pack_w_kernel, dim3(Npad), dim3(256), 0, st, P, Ppad, (const float2*)W, w_packed);
+    CHEST_LDS_OPT_IN(ctx, LDS_GEMM3M, cgemm_w_kernel_3m, T3_LDS_BYTES);
+    hipLaunchKernelGGL(cgemm_w_kernel_3m, dim3(Npad / T2_N, Mpad / T2_M), dim3(256), T3_LDS_BYTES, st, P, Ppad, M, Ppad,
+                       (const float2*)w_packed, h_in, h_out);
     const size_t lds = (size_t)P * sizeof(float2);
     CHEST_LDS_OPT_IN(ctx, LDS_INTERP, interp_from_pilots_kernel, lds);
     hipLaunchKernelGGL(interp_from_pilots_kernel, dim3(M), dim3(256), lds, st, f.S, f.R, f.T, f.nsc, Ppad, ctx->d_patterns,
@@ -726,19 +442,11 @@ int chest_estimate_dense(chest_ctx* ctx, void* stream, int32_t B, const float* r
     const int Mpad = pad128(M), Gpad = pad128(f.G);
     float2* h_in = (float2*)h_scratch;
     float* a_packed = (float*)(h_in + (size_t)Mpad * Ppad);
-    const char* gv = getenv("CHEST_DENSE");      // A/B switch: "1" = first-generation 64x64 tile reading A in place
-    if (gv && gv[0] == '1') {
-        hipLaunchKernelGGL(gather_ls_kernel, dim3(M), dim3(256), 0, st, f.S, f.R, f.T, f.nsc, P, Ppad, M, pd.pilot_idx,
-                           (const float2*)rx4d, (const float2*)tx_pilots, pilot_stride, h_in);
-        hipLaunchKernelGGL(dense_interp_kernel, dim3((f.G + GB_N - 1) / GB_N, (M + GB_M - 1) / GB_M), dim3(256), 0, st, f.S, f.R,
-                           f.T, f.nsc, P, Ppad, M, A, (const float2*)h_in, (float2*)H_est);
-    } else {
-        hipLaunchKernelGGL(gather_ls_kernel, dim3(Mpad), dim3(256), 0, st, f.S, f.R, f.T, f.nsc, P, Ppad, M, pd.pilot_idx,
-                           (const float2*)rx4d, (const float2*)tx_pilots, pilot_stride, h_in);
-        hipLaunchKernelGGL(pack_a_kernel, dim3(Gpad), dim3(256), 0, st, f.G, P, Ppad, A, a_packed);
-        hipLaunchKernelGGL(dense_interp_kernel_v2, dim3(Gpad / T2_N, Mpad / T2_M), dim3(256), D2_LDS_BYTES, st, f.S, f.R, f.T,
-                           f.nsc, Ppad, M, (const float*)a_packed, (const float2*)h_in, (float2*)H_est);
-    }
+    hipLaunchKernelGGL(gather_ls_kernel, dim3(Mpad), dim3(256), 0, st, f.S, f.R, f.T, f.nsc, P, Ppad, M, pd.pilot_idx,
+                       (const float2*)rx4d, (const float2*)tx_pilots, pilot_stride, h_in);
+    hipLaunchKernelGGL(pack_a_kernel, dim3(Gpad), dim3(256), 0, st, f.G, P, Ppad, A, a_packed);
+    hipLaunchKernelGGL(dense_interp_kernel, dim3(Gpad / T2_N, Mpad / T2_M), dim3(256), D2_LDS_BYTES, st, f.S, f.R, f.T,
+                       f.nsc, Ppad, M, (const float*)a_packed, (const float2*)h_in, (float2*)H_est);
     CHEST_HIP(hipGetLastError());
     return CHEST_OK;
 }

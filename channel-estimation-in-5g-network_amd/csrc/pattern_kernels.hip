@@ -43,6 +43,7 @@ struct PatBuildArgs {
     uint64_t seed;
     int32_t idx_stride, first_slot, S, nsc, method, Pcap;
     int32_t* simp_out;            // optional [count][2*Pcap][3]
+    int32_t* nbr_out;             // optional [count][2*Pcap][3]: triangle across the edge opposite each vertex, -1 on the hull
     int32_t* nsimp_out;           // optional [count]
     int32_t* status;
 };
@@ -488,6 +489,13 @@ pattern_build_kernel(const PatBuildArgs A) {
     if (A.simp_out != nullptr) {
         int32_t* so = A.simp_out + (size_t)j * 2 * A.Pcap * 3;
         for (int t = tid; t < ntri; t += PB_THREADS) { so[3 * t] = tv0[t]; so[3 * t + 1] = tv1[t]; so[3 * t + 2] = tv2[t]; }
+        if (A.nbr_out != nullptr) {
+            int32_t* no = A.nbr_out + (size_t)j * 2 * A.Pcap * 3;
+            for (int t = tid; t < ntri; t += PB_THREADS) {
+                no[3 * t] = tn0[t] == TNONE ? -1 : (int)tn0[t]; no[3 * t + 1] = tn1[t] == TNONE ? -1 : (int)tn1[t];
+                no[3 * t + 2] = tn2[t] == TNONE ? -1 : (int)tn2[t];
+            }
+        }
         if (tid == 0 && A.nsimp_out) A.nsimp_out[j] = ntri;
     }
 
@@ -563,7 +571,7 @@ using namespace chest;
 
 extern "C" int chest_patterns_build(chest_ctx* ctx, void* stream, int32_t first_slot, int32_t count, const int32_t* num_pilots,
                                     const int32_t* pilot_idx, int32_t idx_stride, uint64_t seed, const uint64_t* pattern_ids,
-                                    int32_t method, int32_t* simplices_out, int32_t* num_simplices_out) {
+                                    int32_t method, int32_t* simplices_out, int32_t* num_simplices_out, int32_t* neighbors_out) {
     if (!ctx || first_slot < 0 || count < 0 || first_slot + (int64_t)count > (1 << 24) || (count > 0 && !num_pilots)) {
         set_error("chest_patterns_build: bad argument");
         return CHEST_EINVAL;
@@ -613,7 +621,7 @@ extern "C" int chest_patterns_build(chest_ctx* ctx, void* stream, int32_t first_
         pl.o_plan = up(pl.o_pil + (size_t)Pmax * 4, 256);
         pl.stride = up(pl.o_plan + (size_t)G * sizeof(PlanRec), 256);
         if (hipMalloc((void**)&pl.block, pl.stride * (size_t)count) != hipSuccess) { set_error("chest_patterns_build: out of device memory (%zu B)", pl.stride * (size_t)count); return CHEST_ENOMEM; }
-        if (hipMalloc((void**)&pl.d_meta, (size_t)count * (sizeof(int32_t) + sizeof(uint64_t))) != hipSuccess) { (void)hipFree(pl.block); set_error("out of device memory"); return CHEST_ENOMEM; }
+        if (hipMalloc((void**)&pl.d_meta, up((size_t)count * sizeof(int32_t), 8) + (size_t)count * sizeof(uint64_t)) != hipSuccess) { (void)hipFree(pl.block); set_error("out of device memory"); return CHEST_ENOMEM; }
         ctx->pools.push_back(pl);
         pool = &ctx->pools.back();
         // make sure the device table covers the range
@@ -640,7 +648,7 @@ extern "C" int chest_patterns_build(chest_ctx* ctx, void* stream, int32_t first_
     a.table = ctx->d_patterns; a.pool = (unsigned char*)pool->block; a.stride = pool->stride; a.o_pil = pool->o_pil; a.o_plan = pool->o_plan;
     a.num_pilots = d_np; a.given_idx = pilot_idx; a.pattern_ids = d_ids; a.seed = seed; a.idx_stride = idx_stride;
     a.first_slot = first_slot; a.S = ctx->fp.S; a.nsc = ctx->fp.nsc; a.method = method; a.Pcap = pool->Pcap;
-    a.simp_out = simplices_out; a.nsimp_out = num_simplices_out; a.status = ctx->d_status;
+    a.simp_out = simplices_out; a.nbr_out = simplices_out ? neighbors_out : nullptr; a.nsimp_out = num_simplices_out; a.status = ctx->d_status;
     if (simplices_out && pool->Pcap != Pmax) { set_error("chest_patterns_build: simplices_out needs a fresh slot range (row stride is 2*Pmax*3)"); return CHEST_EINVAL; }
     const size_t lds_run = pattern_build_lds_bytes(G, pool->Pcap);
     CHEST_LDS_OPT_IN(ctx, LDS_DELAUNAY, pattern_build_kernel, lds_run);

@@ -211,20 +211,25 @@ class Engine:
             if idx_t.dim() != 2 or idx_t.shape[0] != count:
                 raise ValueError("pilot_idx must be [count, stride]")
             stride = idx_t.shape[1]
-        simp = cnt = None
+        simp = cnt = nbr = None
         if return_simplices:
             simp = torch.zeros(count, 2 * int(npil.max()), 3, dtype=torch.int32, device=self.device)
+            nbr = torch.full_like(simp, -1)
             cnt = torch.zeros(count, dtype=torch.int32, device=self.device)
         N.check(N.lib().chest_patterns_build(self._h, self._stream(), int(first_slot), count, npil.ctypes.data,
                                              None if idx_t is None else idx_t.data_ptr(), int(stride), int(seed) & (2**64 - 1),
                                              None if ids is None else ids.ctypes.data, self.METHOD_CODES[method],
-                                             None if simp is None else simp.data_ptr(), None if cnt is None else cnt.data_ptr()),
+                                             None if simp is None else simp.data_ptr(), None if cnt is None else cnt.data_ptr(),
+                                             None if nbr is None else nbr.data_ptr()),
                 "chest_patterns_build")
         for i in range(count):
             self._slot_P[int(first_slot) + i] = int(npil[i])
         self._next_slot = max(self._next_slot, int(first_slot) + count)
         slots = np.arange(first_slot, first_slot + count, dtype=np.int32)
-        return (slots, simp, cnt) if return_simplices else slots
+        if return_simplices:
+            self._last_neighbors = nbr
+            return slots, simp, cnt
+        return slots
 
     def get_pilots(self, slot: int) -> np.ndarray:
         """Sorted flat pilot indices of a slot (host copy; synchronises)."""
@@ -533,14 +538,36 @@ class Engine:
         return torch.empty(N.lib().chest_mmse_full_apply_scratch_bytes(self.num_pilots(slot), int(num_grids)), dtype=torch.uint8,
                            device=self.device)
 
+    def cubic_operator_from_triangulation(self, slot, simplices, neighbors):
+        """Dense Clough-Tocher operator A [G, P] (float32, device) of the pattern in ``slot``, built ON THE DEVICE from a
+        triangulation: ``simplices`` / ``neighbors`` int32 [n, 3] (host or device) in scipy.spatial.Delaunay's conventions
+        (Qhull's to reproduce the reference, or build_patterns(..., return_simplices=True)'s own)."""
+        simp = self._dev(simplices, torch.int32)
+        nbr = self._dev(neighbors, torch.int32)
+        if simp.dim() != 2 or simp.shape[1] != 3 or tuple(nbr.shape) != tuple(simp.shape):
+            raise ValueError("simplices and neighbors must be equally shaped (n, 3) integer arrays")
+        P = self.num_pilots(slot)
+        A = torch.empty(self.geom.grid, P, dtype=torch.float32, device=self.device)
+        nbytes = N.lib().chest_cubic_workspace_bytes(self._h, P)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        N.check(N.lib().chest_cubic_operator(self._h, self._stream(), int(slot), simp.data_ptr(), nbr.data_ptr(), simp.shape[0],
+                                             A.data_ptr(), ws.data_ptr(), nbytes), "chest_cubic_operator")
+        torch.cuda.current_stream(self.device).synchronize()       # ws is freed on return
+        return A
+
     def cubic_operator(self, pilot_idx):
-        """Device copy of the dense Clough-Tocher operator of a pattern (cached, least recently used of 4 dropped)."""
+        """Device copy of the dense Clough-Tocher operator of a pattern (cached, least recently used of 4 dropped): Qhull's
+        triangulation from the host (scipy.spatial.Delaunay, ~3 ms; its choice among co-circular lattice points is what
+        the reference's values depend on), everything after it -- gradient system, its float64 solve, the patch
+        coefficients of every resource element -- on the device (chest_cubic_operator)."""
         key = interp_plan.pattern_key(pilot_idx, "cubic")
         hit = self._dense.get(key)
         if hit is None:
             S, nsc = self.geom.num_symbols, self.geom.num_sc
             ps, pk = np.unravel_index(np.asarray(pilot_idx, dtype=np.int64), (S, nsc))
-            hit = torch.from_numpy(interp_plan.cubic_operator(ps, pk, S, nsc)).to(self.device)
+            simp, nbr = interp_plan.delaunay_with_neighbors(ps, pk)
+            slot = self.pattern_slot(pilot_idx, "linear", plan=simp)
+            hit = self.cubic_operator_from_triangulation(slot, simp, nbr)
             if len(self._dense) >= 4:
                 self._dense.pop(next(iter(self._dense)))
         else:

@@ -42,6 +42,13 @@ def linear_triangulation(pilot_sym, pilot_sc):
     return np.ascontiguousarray(Delaunay(pts).simplices, dtype=np.int32)
 
 
+def delaunay_with_neighbors(pilot_sym, pilot_sc):
+    """(simplices, neighbors) int32 [n, 3] of scipy.spatial.Delaunay(pilot positions): what CloughTocher2DInterpolator works on."""
+    from scipy.spatial import Delaunay
+    tri = Delaunay(np.column_stack([np.asarray(pilot_sym), np.asarray(pilot_sc)]).astype(np.float64))
+    return np.ascontiguousarray(tri.simplices, dtype=np.int32), np.ascontiguousarray(tri.neighbors, dtype=np.int32)
+
+
 def linear_plan(pilot_sym, pilot_sc, S, nsc):
     """Plan equal to griddata(..., method='linear', fill_value=0.0).  Raises scipy's QhullError for
     degenerate pilot sets (fewer than 3 pilots, all collinear), like the reference does."""
@@ -85,8 +92,9 @@ def cubic_operator(pilot_sym, pilot_sc, S, nsc):
     'cubic' = scipy's CloughTocher2DInterpolator: Qhull Delaunay (same triangulation as 'linear'), global gradient
     estimation at the pilots (iterative, tol 1e-6), then a C1 piecewise-cubic Bezier patch per triangle.  Every step is
     linear in the pilot values, so the interpolator applied to the identity gives the operator (measured 7e-7..1.5e-6
-    relative against griddata on real data: the gradient solver's own tolerance).  About 3 s per full-size pattern on
-    one core; cached per pattern, applied on the GPU as a real x complex MFMA GEMM."""
+    relative against griddata on real data: the gradient solver's own tolerance).  About 1-3 s per full-size pattern on
+    one core.  HOST CROSS-CHECK ONLY: the product builds the operator on the device (Engine.cubic_operator ->
+    chest_cubic_operator); tests compare the two."""
     from scipy.interpolate import CloughTocher2DInterpolator
     ps = np.ascontiguousarray(pilot_sym, dtype=np.int64)
     pk = np.ascontiguousarray(pilot_sc, dtype=np.int64)

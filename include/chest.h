@@ -162,12 +162,14 @@ int chest_pattern_set_triangulation(chest_ctx* ctx, int32_t slot, const int32_t*
  *            1 'nearest': nearest pilot by squared lattice distance, ties to the smaller pilot ordinal;
  *           -1 no plan (simulation only).
  *   num_pilots, pattern_ids: HOST arrays [count].  simplices_out (optional, DEVICE int32 [count][2*Pmax][3], Pmax =
- *   max num_pilots) / num_simplices_out (DEVICE int32 [count]) receive the triangulations.
+ *   max num_pilots) / num_simplices_out (DEVICE int32 [count]) / neighbors_out (optional with simplices_out, same shape: the
+ *   triangle across the edge opposite each vertex, -1 on the hull -- scipy.spatial.Delaunay's convention) receive the
+ *   triangulations.
  * The slots' storage is one pool allocation; rebuilding the same slot range with no larger patterns reuses it in place,
  * ordered on `stream` (no synchronisation, no allocation), which is how a per-frame-pattern producer loop uses it. */
 int chest_patterns_build(chest_ctx* ctx, void* stream, int32_t first_slot, int32_t count, const int32_t* num_pilots,
                          const int32_t* pilot_idx, int32_t idx_stride, uint64_t seed, const uint64_t* pattern_ids,
-                         int32_t method, int32_t* simplices_out, int32_t* num_simplices_out);
+                         int32_t method, int32_t* simplices_out, int32_t* num_simplices_out, int32_t* neighbors_out);
 /* Sorted flat pilot indices of a slot back to the HOST (int32 [P]); synchronises. */
 int chest_pattern_get_pilots(chest_ctx* ctx, int32_t slot, int32_t* pilot_idx_out);
 /* Read a slot's plan back in chest_pattern_set's layout: HOST plan_idx uint16[3][G], plan_w float[3][G]. */
@@ -284,7 +286,8 @@ int chest_qam_demodulate(chest_ctx* ctx, void* stream, int32_t M, int64_t num_sy
 int chest_bit_errors(chest_ctx* ctx, void* stream, int64_t n, const uint8_t* a, const uint8_t* b, uint64_t* count);
 
 /* Full-covariance MMSE (MMSEEstimator(channel_covariance=R, estimate_statistics=False), :181-190).
- * prepare: W = R (R + sigma^2 I)^-1 in float64 on the device (blocked Cholesky), stored as c64
+ * prepare: W = R (R + sigma^2 I)^-1 = I - sigma^2 (R + sigma^2 I)^-1 in float64 on the device (in-place Gauss-Jordan
+ *          inversion of the Hermitian positive definite R + sigma^2 I, no pivoting), stored as c64
  *          W [P][P]; cov is DEVICE complex128 [P][P] (interleaved doubles).
  * apply  : h_mmse = W h_ls for B*R*T right-hand sides on the f32 MFMA pipe, then interpolation with
  *          the slot's plan -> H_est [B][S][R][T][nsc]. */
@@ -306,10 +309,20 @@ int chest_mmse_full_apply(chest_ctx* ctx, void* stream, int32_t num_frames, cons
 int chest_mmse_full_apply_pilots(chest_ctx* ctx, void* stream, int32_t num_frames, const float* h_ls_pilots,
                                  int32_t h_ls_stride, int32_t pattern_slot, const float* W, float* h_scratch, float* H_est);
 
+/* Dense Clough-Tocher ('cubic') operator of a pattern, built ON THE DEVICE from a triangulation (griddata(method='cubic') =
+ * scipy.interpolate.CloughTocher2DInterpolator, reached through src/baseline_estimators.py:65-79): global gradient
+ * estimation at the pilots as a direct float64 solve of the system SciPy iterates on, then the C1 piecewise-cubic patch of
+ * every resource element's triangle -> A [G][P] float32 (DEVICE out), 0 outside the hull.  simplices / neighbors: DEVICE int32
+ * [num_simplices][3] pilot ordinals / adjacent triangles (-1 on the hull) -- scipy.spatial.Delaunay(...).simplices /
+ * .neighbors to reproduce the reference, or the output of chest_patterns_build.  workspace: DEVICE,
+ * chest_cubic_workspace_bytes(ctx, P) bytes.  Within ~6e-7 of SciPy's interpolator (its own solver tolerance). */
+int64_t chest_cubic_workspace_bytes(chest_ctx* ctx, int32_t num_pilots);
+int chest_cubic_operator(chest_ctx* ctx, void* stream, int32_t pattern_slot, const int32_t* simplices, const int32_t* neighbors,
+                         int32_t num_simplices, float* A, void* workspace, int64_t workspace_bytes);
+
 /* LSEstimator('cubic').estimate (src/baseline_estimators.py:65-79 with method='cubic' = scipy Clough-Tocher): the
- * interpolation is a dense linear operator A [G][P] float32 (DEVICE; built on the host once per pattern from scipy's own
- * interpolator, see interp_plan.cubic_operator), applied to the LS pilot estimates of all B*R*T grids as a real x complex
- * GEMM on the f32 MFMA pipe.  h_scratch: DEVICE, chest_estimate_dense_scratch_bytes(ctx, P, B*R*T) bytes (gathered h_ls and
+ * interpolation is a dense linear operator A [G][P] float32 (DEVICE; chest_cubic_operator), applied to the LS pilot
+ * estimates of all B*R*T grids as a real x complex GEMM on the f32 MFMA pipe.  h_scratch: DEVICE, chest_estimate_dense_scratch_bytes(ctx, P, B*R*T) bytes (gathered h_ls and
  * A repacked to the GEMM's tile padding). */
 int64_t chest_estimate_dense_scratch_bytes(chest_ctx* ctx, int32_t num_pilots, int32_t num_grids);
 int chest_estimate_dense(chest_ctx* ctx, void* stream, int32_t num_frames, const float* rx4d, const float* tx_pilots,
