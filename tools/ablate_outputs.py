@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Frame-kernel time by requested output subset, one process, one set of buffers (first allocation):
-which part of the step is synthesis, which is stores.  `--rg` sets the slab's rx group, `--legacy` the old row path."""
+which part of the step is synthesis, which is stores.  `--rg` sets the slab rx group, `--min-waves 4` the 128-VGPR instantiation."""
 import argparse
 import importlib
 import os
