@@ -220,13 +220,15 @@ def _cpu_frames(args):
 # =====================================================================================================
 def _pmc_traffic(workload, F, group):
     """HBM bytes per frame-kernel launch from the committed PMC passes (profiles/pmc_traffic.json), only when the
-    record was collected on the CURRENT kernel source (sha of csrc/frame_kernel.hip) and this workload; else None."""
+    record was collected on the CURRENT kernel sources (sha of csrc/frame_kernel.hip and csrc/frame_slab_kernel.hip) and
+    this workload; else None."""
     import hashlib
     tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         rec = json.load(open(tfile))
-        sha = hashlib.sha256(open(os.path.join(ROOT, PKG, "csrc", "frame_kernel.hip"), "rb").read()).hexdigest()[:16]
-        if rec.get("workload") == workload and rec.get("frames") == F and group == PATTERN_GROUP and rec.get("kernel_source_sha16") == sha:
+        sha = lambda f: hashlib.sha256(open(os.path.join(ROOT, PKG, "csrc", f), "rb").read()).hexdigest()[:16]
+        if rec.get("workload") == workload and rec.get("frames") == F and group == PATTERN_GROUP and \
+                rec.get("kernel_source_sha16") == sha("frame_kernel.hip") and rec.get("frame_slab_kernel_sha16") == sha("frame_slab_kernel.hip"):
             return rec.get("hbm_bytes_per_launch"), f"profiles/pmc_traffic.json @ {rec.get('commit', '?')}"
     except Exception:
         pass
@@ -478,7 +480,7 @@ def run(args):
             achieved = bytes_frame * F / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
             traffic, tsrc = _pmc_traffic(args.workload, F, group)
             roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": tsrc, "kernel": "frame_kernel",
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": tsrc, "kernel": "frame_slab_kernel",
                     "kernel_ms": kern_ms, "taps_kernel_ms": taps_ms, "call_ms": call_ms, "bytes_per_frame": bytes_frame}
         s = summ.cpu().numpy()
         res = {
