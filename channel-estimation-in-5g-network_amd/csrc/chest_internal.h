@@ -102,7 +102,7 @@ void set_error(const char* fmt, ...);
     } while (0)
 
 enum { LDS_TAPS = 0, LDS_FRAME = 1, LDS_ESTIMATE = 2, LDS_INTERP = 3, LDS_GEMM = 4, LDS_GEMM3M = 5, LDS_FRAME_640 = 6,
-       LDS_FRAME_1024 = 7, LDS_FRAME_ROWS = 8, LDS_DELAUNAY = 9, LDS_FRAME_44 = 10, LDS_FRAME_11 = 11, LDS_FRAME_GEN = 12, LDS_FRAME_W5 = 13, LDS_GJ_PANEL = 14, LDS_GJ_UPDATE = 15, LDS_GJ_PANEL_R = 16, LDS_GJ_UPDATE_R = 17 };
+       LDS_FRAME_1024 = 7, LDS_FRAME_ROWS = 8, LDS_DELAUNAY = 9, LDS_FRAME_44 = 10, LDS_FRAME_11 = 11, LDS_FRAME_GEN = 12, LDS_FRAME_W5 = 13, LDS_GJ_PANEL = 14, LDS_GJ_UPDATE = 15, LDS_GJ_PANEL_R = 16, LDS_GJ_UPDATE_R = 17, LDS_FRAME_640_44 = 18, LDS_INTERP_TFOLD = 19 };
 
 // RAII: make the context's device current for the duration of an entry point and restore the caller's afterwards
 struct DeviceGuard {

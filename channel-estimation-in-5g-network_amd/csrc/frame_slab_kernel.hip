@@ -636,7 +636,10 @@ int launch_k2_slab(chest_ctx* ctx, hipStream_t st, int32_t B, const chest_frame_
         }
         return launch_one<320, 4, 0, 0, 0, true>(ctx, LDS_FRAME_GEN, CHEST_SLAB_ARGS);
     }
-    if (nwave <= 10) return launch_one<640, 3, 0, 0, 0, true>(ctx, LDS_FRAME_640, CHEST_SLAB_ARGS);
+    if (nwave <= 10) {                     // the 2048-FFT grids (nsc <= 1280)
+        if (!injected && !(fp.half & 1) && T == 4 && R == 4 && RG == 1) return launch_one<640, 3, 4, 4, 1, false>(ctx, LDS_FRAME_640_44, CHEST_SLAB_ARGS);
+        return launch_one<640, 3, 0, 0, 0, true>(ctx, LDS_FRAME_640, CHEST_SLAB_ARGS);
+    }
     return launch_one<1024, 4, 0, 0, 0, true>(ctx, LDS_FRAME_1024, CHEST_SLAB_ARGS);
 #undef CHEST_SLAB_ARGS
 }

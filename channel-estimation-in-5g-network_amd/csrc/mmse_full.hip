@@ -187,6 +187,53 @@ interp_from_pilots_kernel(int S, int R, int T, int nsc, int Ppad, const PatternD
     }
 }
 
+// The tx-replicated form of the pipeline route (one workgroup per (frame, rx)) with the frame kernel's write path: a symbol's
+// nsc interpolated values are staged in LDS once, and the T identical rows H_est[b][s][r][0..T) -- ONE contiguous span of
+// T * nsc elements -- leave as consecutive 128-B-line-aligned 1 KiB wave stores that read the LDS row modulo nsc.
+typedef float v4f_i __attribute__((ext_vector_type(4)));
+typedef float v2f_i __attribute__((ext_vector_type(2)));
+__global__ void __launch_bounds__(256)
+interp_from_pilots_tfold_kernel(int S, int R, int T, int nsc, int Ppad, const PatternDev* __restrict__ patterns, int slot,
+                                const float2* __restrict__ h, float2* __restrict__ H_est) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    const PatternDev pat = patterns[slot];
+    const int P = pat.P, m = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float2* hp = (float2*)lds_raw;                                  // [P rounded up to even]
+    float2* row = hp + ((P + 1) & ~1);                              // [nsc]
+    const int r = m % R, b = m / R;
+    for (int i = tid; i < P; i += blockDim.x) hp[i] = h[(size_t)m * Ppad + i];
+    const PlanRec* __restrict__ plan = (const PlanRec*)pat.plan;
+    const int n = T * nsc;
+    const float inv_nsc = 1.0f / (float)nsc;
+    for (int s = 0; s < S; ++s) {
+        __syncthreads();                                            // hp ready / previous symbol's row fully read
+        for (int k = tid; k < nsc; k += blockDim.x) row[k] = interp(plan[s * nsc + k], hp, 1, 0);
+        __syncthreads();
+        float2* __restrict__ g0 = H_est + ((size_t)(b * S + s) * R + r) * T * nsc;
+        const int head = (int)(((uintptr_t)g0 & 127u) >> 3);
+        const int nst = (head + n + 127) >> 7;
+        for (int q = wave; q < nst; q += 4) {
+            const int e = (q << 7) - head + 2 * lane;
+            if (e >= -1 && e < n) {
+                const int ec = e < 0 ? 0 : e;
+                int i0 = ec - (int)((float)ec * inv_nsc) * nsc;         // ec mod nsc (float quotient may be off by one)
+                if (i0 < 0) i0 += nsc;
+                if (i0 >= nsc) i0 -= nsc;
+                if (e >= 0 && e + 1 < n) {
+                    const int i1 = i0 + 1 == nsc ? 0 : i0 + 1;
+                    const float2 a = row[i0], c = row[i1];
+                    const v4f_i v = {a.x, a.y, c.x, c.y};
+                    __builtin_nontemporal_store(v, (v4f_i*)(g0 + e));
+                } else {                                             // e == -1: element 0 alone; e == n - 1: last element alone
+                    const float2 a = e < 0 ? row[0] : row[i0];
+                    const v2f_i v = {a.x, a.y};
+                    __builtin_nontemporal_store(v, (v2f_i*)(g0 + ec));
+                }
+            }
+        }
+    }
+}
+
 // h_ls_pilots [M][stride] (as chest_frames_run writes it) -> GEMM A operand [Mpad][Ppad], zero padded
 __global__ void __launch_bounds__(256)
 pack_h_kernel(int M, int P, int stride, int Ppad, const float2* __restrict__ h, float2* __restrict__ hp) {
@@ -406,11 +453,12 @@ int chest_mmse_full_apply_pilots(chest_ctx* ctx, void* stream, int32_t B, const 
     hipLaunchKernelGGL(cgemm_w_kernel_3m, dim3(Npad / T2_N, Mpad / T2_M), dim3(256), T3_LDS_BYTES, st, P, Ppad, M, Ppad,
                        (const float2*)w_packed, h_in, h_out);
     prof_close(ctx, st, sp_gemm);
-    const size_t lds = (size_t)P * sizeof(float2);
-    CHEST_LDS_OPT_IN(ctx, LDS_INTERP, interp_from_pilots_kernel, lds);
+    const size_t lds = ((size_t)((P + 1) & ~1) + (size_t)f.nsc) * sizeof(float2);
+    if (((uintptr_t)H_est & 15) != 0) { set_error("chest_mmse_full_apply_pilots: H_est must be 16-byte aligned"); return CHEST_EINVAL; }
+    CHEST_LDS_OPT_IN(ctx, LDS_INTERP_TFOLD, interp_from_pilots_tfold_kernel, lds);
     const int sp_int = prof_open(ctx, st, CHEST_K_INTERP);
-    hipLaunchKernelGGL(interp_from_pilots_kernel, dim3(M), dim3(256), lds, st, f.S, f.R, f.T, f.nsc, Ppad, ctx->d_patterns,
-                       slot, h_out, (float2*)H_est, 1);
+    hipLaunchKernelGGL(interp_from_pilots_tfold_kernel, dim3(M), dim3(256), lds, st, f.S, f.R, f.T, f.nsc, Ppad, ctx->d_patterns,
+                       slot, h_out, (float2*)H_est);
     prof_close(ctx, st, sp_int);
     CHEST_HIP(hipGetLastError());
     return CHEST_OK;
