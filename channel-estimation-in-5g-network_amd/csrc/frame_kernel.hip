@@ -46,6 +46,7 @@ taps_kernel(const FrameParams* __restrict__ fpp, const chest_frame_desc* __restr
     float2* osc = (float2*)lds_raw;                              // [nt*T*R*20]
     float2* csum_l = osc + (size_t)KT * T * R * CHEST_NUM_OSC;   // [S*R*KTS]
     float* red = (float*)(csum_l + (size_t)S * R * KTS);         // [32]
+    float2* Ql = (float2*)(red + 32);                            // [KT*KT] Gram matrix of this frame's profile
     float2* c_g = (float2*)(rec + ST_SCAL);                      // [S][KTS][R][T]   (state_c_index)
     float2* csum_g = c_g + (size_t)S * R * T * KTS;              // [S][KTS][R]      (state_csum_index)
     const uint64_t frame = frame_offset + (uint64_t)b;
@@ -103,6 +104,7 @@ taps_kernel(const FrameParams* __restrict__ fpp, const chest_frame_desc* __restr
     __syncthreads();                                             // workgroup-scope visibility of c_g
 
     // ---- tx-summed taps (every TX sends the same grid, quirk Q5) ----------------------------------------
+    for (int j = tid; j < KT * KT; j += nthr) Ql[j] = gram[(size_t)fd.channel_type * KT * KT + j];
     for (int j = tid; j < S * R * KTS; j += nthr) {
         const int d = j % KTS, sr = j / KTS;
         float2 acc = make_float2(0.f, 0.f);
@@ -113,20 +115,32 @@ taps_kernel(const FrameParams* __restrict__ fpp, const chest_frame_desc* __restr
     __syncthreads();
 
     // ---- analytic powers: sum_k |sum_d a_d W_d[k]|^2 = sum_{d,d'} a_d conj(a_d') Q[d][d'] ----------------
-    const float2* Q = gram + (size_t)fd.channel_type * KT * KT;
+    // One item per gain a_d1 (memory order of the record: coalesced, one run-time division per item); the inner sum
+    // over d2 walks the same (s, r[, t]) column of the record at stride R*T.
     float p_y = 0.f, p_h = 0.f;
-    for (int j = tid; j < S * R * nt * nt; j += nthr) {
-        const int d2 = j % nt, d1 = (j / nt) % nt, sr = j / (nt * nt);
-        const float2 a = csum_l[sr * KTS + d1], bq = csum_l[sr * KTS + d2], q = Q[d1 * KT + d2];
-        const float2 ab = make_float2(a.x * bq.x + a.y * bq.y, a.y * bq.x - a.x * bq.y);   // a * conj(b)
-        p_y += ab.x * q.x - ab.y * q.y;
+    for (int j = tid; j < S * R * KTS; j += nthr) {
+        const int d1 = j % KTS, sr = j / KTS;
+        if (d1 >= nt) continue;
+        const float2 a = csum_l[j];
+        float2 acc = make_float2(0.f, 0.f);                      // sum_d2 conj(b_d2) Q[d1][d2]
+        for (int d2 = 0; d2 < nt; ++d2) {
+            const float2 bq = csum_l[sr * KTS + d2], q = Ql[d1 * KT + d2];
+            acc.x += bq.x * q.x + bq.y * q.y; acc.y += bq.x * q.y - bq.y * q.x;
+        }
+        p_y += a.x * acc.x - a.y * acc.y;
     }
-    for (int j = tid; j < S * R * T * nt * nt; j += nthr) {
-        const int d2 = j % nt, d1 = (j / nt) % nt, q0 = j / (nt * nt);
-        const int s_ = q0 / (R * T), r_ = (q0 / T) % R, t_ = q0 % T;
-        const float2 a = c_g[state_c_index(s_, d1, r_, t_, R, T)], bq = c_g[state_c_index(s_, d2, r_, t_, R, T)], q = Q[d1 * KT + d2];
-        const float2 ab = make_float2(a.x * bq.x + a.y * bq.y, a.y * bq.x - a.x * bq.y);
-        p_h += ab.x * q.x - ab.y * q.y;
+    const int RT = R * T;
+    for (int j = tid; j < S * KTS * RT; j += nthr) {
+        const int d1 = (j / RT) % KTS;
+        if (d1 >= nt) continue;
+        const float2 a = c_g[j];
+        const float2* __restrict__ col = c_g + (j - d1 * RT);    // tap 0 of this (s, r, t)
+        float2 acc = make_float2(0.f, 0.f);
+        for (int d2 = 0; d2 < nt; ++d2) {
+            const float2 bq = col[d2 * RT], q = Ql[d1 * KT + d2];
+            acc.x += bq.x * q.x + bq.y * q.y; acc.y += bq.x * q.y - bq.y * q.x;
+        }
+        p_h += a.x * acc.x - a.y * acc.y;
     }
     p_y = block_sum(p_y, red);
     p_h = block_sum(p_h, red);
@@ -163,7 +177,7 @@ int launch_frames(chest_ctx* ctx, hipStream_t st, int32_t B, const chest_frame_d
         if (((uintptr_t)q & 15) != 0) { set_error("chest_frames_run: output/workspace pointers must be 16-byte aligned"); return CHEST_EINVAL; }
     int Pmax = 1;
     for (const auto& p : ctx->patterns) Pmax = p.dev.P > Pmax ? p.dev.P : Pmax;
-    const size_t lds1 = ((size_t)KT * fp.T * fp.R * CHEST_NUM_OSC + (size_t)fp.S * fp.R * KTS) * sizeof(float2) + 32 * sizeof(float);
+    const size_t lds1 = ((size_t)KT * fp.T * fp.R * CHEST_NUM_OSC + (size_t)fp.S * fp.R * KTS + (size_t)KT * KT) * sizeof(float2) + 32 * sizeof(float);
     if (lds1 > 160 * 1024) { set_error("taps kernel needs %zu B of LDS (> 160 KiB): too many antennas", lds1); return CHEST_EINVAL; }
     CHEST_LDS_OPT_IN(ctx, LDS_TAPS, taps_kernel, lds1);
     chest_injected inj_v{};
