@@ -93,9 +93,9 @@ struct SlabArgs {
 
 // LDS slab segment capacities in float2 elements (even, +2 so that a parity shift of one element fits)
 __host__ __device__ inline int slab_seg(int rows, int nsc) { return ((rows * nsc + 1) & ~1) + 2; }
-__host__ __device__ inline int slab_elems(int T, int RG, int nsc) {
-    const int w = slab_seg(T, nsc) + slab_seg(RG * T, nsc) + slab_seg(RG, nsc);
-    const int e = 2 * slab_seg(RG * T, nsc);
+__host__ __device__ inline int slab_elems(int T, int RG, int nsc, int SS) {
+    const int w = slab_seg(SS * T, nsc) + slab_seg(SS * RG * T, nsc) + slab_seg(SS * RG, nsc);
+    const int e = 2 * slab_seg(SS * RG * T, nsc);
     return w > e ? w : e;
 }
 
@@ -105,7 +105,7 @@ __host__ __device__ inline int slab_elems(int T, int RG, int nsc) {
 // exp(-2 pi j delay/N) (needs an even number of used bins below DC: no pair straddles it; the launcher checks), and both
 // barriers of a unit sit back to back behind the long compute stretch.  0 = run-time values: full twiddle registers,
 // rows written to the slab as they are produced.
-template <int NT, int TT, int RR, int RGT, bool INJ>
+template <int NT, int TT, int RR, int RGT, int SS, bool INJ>
 __device__ __forceinline__ void slab_body(const SlabArgs& A) {
     const FrameParams& fp = *A.fp;
     const PatternDev& pat = *A.pat;
@@ -172,7 +172,10 @@ __device__ __forceinline__ void slab_body(const SlabArgs& A) {
         } else return w[d][NW - 1];
     };
 
-    const int seg_tx = 0, seg_h = slab_seg(T, nsc), seg_rx = seg_h + slab_seg(RG * T, nsc);
+    // SSN consecutive symbols form one unit (STAGED instantiations with RG == R only: a unit's spans stay contiguous across
+    // symbols); 1 everywhere else.
+    constexpr int SSN = STAGED ? SS : 1;
+    const int seg_tx = 0, seg_h = slab_seg(SSN * T, nsc), seg_rx = seg_h + slab_seg(SSN * RG * T, nsc);
     const int ngroups = R / RG;
     bool first_unit = true;
     // Store-out crew.  A workgroup of 4n+1 waves puts two of its waves on one SIMD; the younger of them loses the issue
@@ -186,93 +189,120 @@ __device__ __forceinline__ void slab_body(const SlabArgs& A) {
     STAMP_DECL;
     STAMP(st_a);
 
-    // ---- phase W: per unit (symbol, rx group) assemble tx / H / rx rows in the slab, then stream them out ------------
-    uint32_t sl0 = slots[kc0], sl1 = slots[kc1];
-    for (int s = 0; s < S; ++s) {
-        const unsigned s0 = sl0, s1 = sl1;
-        if (s + 1 < S) { sl0 = slots[(s + 1) * nsc + kc0]; sl1 = slots[(s + 1) * nsc + kc1]; }      // one symbol ahead
-        float u0, u1;
-        if (usym != nullptr) {
-            u0 = usym[s0]; u1 = usym[s1];
-        } else {
-            const u32x4 z = draw(A.key, STREAM_SYM, (uint32_t)(s * npair + pr));
-            u0 = u01(z.x); u1 = u01(z.y);
+    // ---- phase W: per unit (symbols, rx group) assemble tx / H / rx rows in the slab, then stream them out -----------
+    uint32_t sln[SSN][2];                                                        // slot entries, one unit ahead
+#pragma unroll
+    for (int ss = 0; ss < SSN; ++ss) {
+        const int sy = ss < S ? ss : S - 1;
+        sln[ss][0] = slots[sy * nsc + kc0]; sln[ss][1] = slots[sy * nsc + kc1];
+    }
+    for (int sb = 0; sb < S; sb += SSN) {
+        const int ns = SSN == 1 ? 1 : min(SSN, S - sb);                          // symbols of this unit (ragged last unit)
+        unsigned sc[SSN][2];
+        float2 xs[SSN][2];
+        bool pp[SSN][2];
+#pragma unroll
+        for (int ss = 0; ss < SSN; ++ss) {
+            sc[ss][0] = sln[ss][0]; sc[ss][1] = sln[ss][1];
+            const int sn = sb + SSN + ss;
+            if (sn < S) { sln[ss][0] = slots[sn * nsc + kc0]; sln[ss][1] = slots[sn * nsc + kc1]; }
+            float u0, u1;
+            if (usym != nullptr) {
+                u0 = usym[sc[ss][0]]; u1 = usym[sc[ss][1]];
+            } else {
+                const u32x4 z = draw(A.key, STREAM_SYM, (uint32_t)((sb + ss) * npair + pr));
+                u0 = u01(z.x); u1 = u01(z.y);
+            }
+            xs[ss][0] = cis_unit(__builtin_amdgcn_fractf(u0));                   // exp(j 2pi u) (:395,:399)
+            xs[ss][1] = cis_unit(__builtin_amdgcn_fractf(u1));
+            pp[ss][0] = act && ss < ns && sc[ss][0] < (unsigned)P; pp[ss][1] = v1 && ss < ns && sc[ss][1] < (unsigned)P;
         }
-        const float2 x0 = cis_unit(__builtin_amdgcn_fractf(u0));                 // exp(j 2pi u) (:395,:399)
-        const float2 x1 = cis_unit(__builtin_amdgcn_fractf(u1));
-        const bool p0 = act && s0 < (unsigned)P, p1 = v1 && s1 < (unsigned)P;
-        const float2* __restrict__ cs = A.c_g + (size_t)s * KTS * R * T;         // this symbol's gains [tap][r][t]
         for (int rg = 0; rg < ngroups; ++rg) {
             const int r0 = rg * RG;
             // global spans of this unit (element offsets inside the frame) and their parities
-            const unsigned e_tx = (unsigned)(s * T) * (unsigned)nsc, e_h = (unsigned)((s * R + r0) * T) * (unsigned)nsc,
-                           e_rx = (unsigned)(s * R + r0) * (unsigned)nsc;
+            const unsigned e_tx = (unsigned)(sb * T) * (unsigned)nsc, e_h = (unsigned)((sb * R + r0) * T) * (unsigned)nsc,
+                           e_rx = (unsigned)(sb * R + r0) * (unsigned)nsc;
             float2* __restrict__ l_tx = slab + seg_tx + ((par_tx + e_tx) & 1);
             float2* __restrict__ l_h = slab + seg_h + ((par_h + e_h) & 1);
             float2* __restrict__ l_rx = slab + seg_rx + ((par_rx + e_rx) & 1);
             if constexpr (STAGED) {
                 // compute the whole unit into registers first: nothing here touches the slab, so this stretch overlaps the
                 // other waves' store-out of the previous unit
-                float2 hv[RGT * TT][2], qv[RGT][2];
+                float2 hv[SSN][RGT * TT][2], qv[SSN][RGT][2];
 #pragma unroll
-                for (int i = 0; i < RGT * TT; ++i) hv[i][0] = hv[i][1] = make_float2(0.f, 0.f);
+                for (int ss = 0; ss < SSN; ++ss) {
+                    if (ss >= ns) continue;
+                    const int s = sb + ss;
+                    const float2* __restrict__ cs = A.c_g + (size_t)s * KTS * R * T;   // this symbol's gains [tap][r][t]
 #pragma unroll
-                for (int d = 0; d < NT; ++d) {
-                    const float2 wa = w[d][0], wb = w_odd(d);
-                    const float2* __restrict__ cd = cs + (d * R + r0) * T;       // [rr][t] contiguous: one scalar load per tap
+                    for (int i = 0; i < RGT * TT; ++i) hv[ss][i][0] = hv[ss][i][1] = make_float2(0.f, 0.f);
 #pragma unroll
-                    for (int i = 0; i < RGT * TT; ++i) {
-                        const float2 c = cd[i];
-                        cfma(hv[i][0], c, wa);
-                        cfma(hv[i][1], c, wb);
+                    for (int d = 0; d < NT; ++d) {
+                        const float2 wa = w[d][0], wb = w_odd(d);
+                        const float2* __restrict__ cd = cs + (d * R + r0) * T;   // [rr][t] contiguous: one scalar load per tap
+#pragma unroll
+                        for (int i = 0; i < RGT * TT; ++i) {
+                            const float2 c = cd[i];
+                            cfma(hv[ss][i][0], c, wa);
+                            cfma(hv[ss][i][1], c, wb);
+                        }
                     }
-                }
 #pragma unroll
-                for (int rr = 0; rr < RGT; ++rr) {
-                    const int r = r0 + rr;
-                    // sum_t H_t is accumulated from the per-tx rows, whether or not H is stored
-                    float2 hs0 = make_float2(0.f, 0.f), hs1 = make_float2(0.f, 0.f);
+                    for (int rr = 0; rr < RGT; ++rr) {
+                        const int r = r0 + rr;
+                        // sum_t H_t is accumulated from the per-tx rows, whether or not H is stored
+                        float2 hs0 = make_float2(0.f, 0.f), hs1 = make_float2(0.f, 0.f);
 #pragma unroll
-                    for (int t = 0; t < TT; ++t) {
-                        hs0.x += hv[rr * TT + t][0].x; hs0.y += hv[rr * TT + t][0].y;
-                        hs1.x += hv[rr * TT + t][1].x; hs1.y += hv[rr * TT + t][1].y;
+                        for (int t = 0; t < TT; ++t) {
+                            hs0.x += hv[ss][rr * TT + t][0].x; hs0.y += hv[ss][rr * TT + t][0].y;
+                            hs1.x += hv[ss][rr * TT + t][1].x; hs1.y += hv[ss][rr * TT + t][1].y;
+                        }
+                        const float2 y0 = cmul(hs0, xs[ss][0]), y1 = cmul(hs1, xs[ss][1]);   // y = sum_t H x (:330-334)
+                        float2 n0v, n1v;
+                        if (nre != nullptr) {
+                            const unsigned row = (unsigned)(s * R + r) * (unsigned)nsc;
+                            n0v = make_float2((nre + row)[kc0], (nim + row)[kc0]);
+                            n1v = make_float2((nre + row)[kc1], (nim + row)[kc1]);
+                        } else {
+                            const u32x4 z = draw(A.key, STREAM_NOISE, (uint32_t)((s * R + r) * npair + pr));
+                            n0v = gauss_pair(z.x, z.y);
+                            n1v = gauss_pair(z.z, z.w);
+                        }
+                        qv[ss][rr][0] = make_float2(fmaf(noise_std, n0v.x, y0.x), fmaf(noise_std, n0v.y, y0.y));
+                        qv[ss][rr][1] = make_float2(fmaf(noise_std, n1v.x, y1.x), fmaf(noise_std, n1v.y, y1.y));
                     }
-                    const float2 y0 = cmul(hs0, x0), y1 = cmul(hs1, x1);         // y = sum_t H x (:330-334)
-                    float2 n0v, n1v;
-                    if (nre != nullptr) {
-                        const unsigned row = (unsigned)(s * R + r) * (unsigned)nsc;
-                        n0v = make_float2((nre + row)[kc0], (nim + row)[kc0]);
-                        n1v = make_float2((nre + row)[kc1], (nim + row)[kc1]);
-                    } else {
-                        const u32x4 z = draw(A.key, STREAM_NOISE, (uint32_t)((s * R + r) * npair + pr));
-                        n0v = gauss_pair(z.x, z.y);
-                        n1v = gauss_pair(z.z, z.w);
-                    }
-                    qv[rr][0] = make_float2(fmaf(noise_std, n0v.x, y0.x), fmaf(noise_std, n0v.y, y0.y));
-                    qv[rr][1] = make_float2(fmaf(noise_std, n1v.x, y1.x), fmaf(noise_std, n1v.y, y1.y));
                 }
                 STAMP_ADD(0);                                                    // W compute
                 if (!first_unit) __syncthreads();                                // previous unit's store-out has read the slab
                 first_unit = false;
                 STAMP_ADD(1);                                                    // W barrier B
                 if (act) {
-                    if (rg == 0 && txb != nullptr) {
 #pragma unroll
-                        for (int t = 0; t < TT; ++t) put(l_tx + t * nsc, x0, x1);
-                    }
+                    for (int ss = 0; ss < SSN; ++ss) {
+                        if (ss >= ns) continue;
+                        if (rg == 0 && txb != nullptr) {
 #pragma unroll
-                    for (int rr = 0; rr < RGT; ++rr) {
-                        const int r = r0 + rr;
-                        if (Hb != nullptr) {
-#pragma unroll
-                            for (int t = 0; t < TT; ++t) put(l_h + (rr * TT + t) * nsc, hv[rr * TT + t][0], hv[rr * TT + t][1]);
+                            for (int t = 0; t < TT; ++t) put(l_tx + (ss * TT + t) * nsc, xs[ss][0], xs[ss][1]);
                         }
-                        if (rxb != nullptr) put(l_rx + rr * nsc, qv[rr][0], qv[rr][1]);
-                        if (p0) hp[s0 * R + r] = pilot_divide(qv[rr][0], x0);    // (src/baseline_estimators.py:110)
-                        if (p1) hp[s1 * R + r] = pilot_divide(qv[rr][1], x1);
+#pragma unroll
+                        for (int rr = 0; rr < RGT; ++rr) {
+                            const int r = r0 + rr;
+                            if (Hb != nullptr) {
+#pragma unroll
+                                for (int t = 0; t < TT; ++t) put(l_h + ((ss * RGT + rr) * TT + t) * nsc, hv[ss][rr * TT + t][0], hv[ss][rr * TT + t][1]);
+                            }
+                            if (rxb != nullptr) put(l_rx + (ss * RGT + rr) * nsc, qv[ss][rr][0], qv[ss][rr][1]);
+                            if (pp[ss][0]) hp[sc[ss][0] * R + r] = pilot_divide(qv[ss][rr][0], xs[ss][0]);    // (src/baseline_estimators.py:110)
+                            if (pp[ss][1]) hp[sc[ss][1] * R + r] = pilot_divide(qv[ss][rr][1], xs[ss][1]);
+                        }
                     }
                 }
             } else {
+                const int s = sb;
+                const float2 x0 = xs[0][0], x1 = xs[0][1];
+                const unsigned s0 = sc[0][0], s1 = sc[0][1];
+                const bool p0 = pp[0][0], p1 = pp[0][1];
+                const float2* __restrict__ cs = A.c_g + (size_t)s * KTS * R * T;     // this symbol's gains [tap][r][t]
                 if (!first_unit) __syncthreads();                                // previous unit's store-out has read the slab
                 first_unit = false;
                 if (act && rg == 0 && txb != nullptr) {
@@ -316,9 +346,9 @@ __device__ __forceinline__ void slab_body(const SlabArgs& A) {
             STAMP_ADD(3);                                                        // W barrier A
             if (storer) {
                 int ph = wave;                                                   // rotate the stores of consecutive segments over the waves
-                if (rg == 0 && txb != nullptr) { const int n = seg_store(txb + e_tx, l_tx, T * nsc, ph, nstw, lane); ph = (ph + nstw - n % nstw) % nstw; }
-                if (Hb != nullptr) { const int n = seg_store(Hb + e_h, l_h, RG * T * nsc, ph, nstw, lane); ph = (ph + nstw - n % nstw) % nstw; }
-                if (rxb != nullptr) seg_store(rxb + e_rx, l_rx, RG * nsc, ph, nstw, lane);
+                if (rg == 0 && txb != nullptr) { const int n = seg_store(txb + e_tx, l_tx, ns * T * nsc, ph, nstw, lane); ph = (ph + nstw - n % nstw) % nstw; }
+                if (Hb != nullptr) { const int n = seg_store(Hb + e_h, l_h, ns * RG * T * nsc, ph, nstw, lane); ph = (ph + nstw - n % nstw) % nstw; }
+                if (rxb != nullptr) seg_store(rxb + e_rx, l_rx, ns * RG * nsc, ph, nstw, lane);
             }
             STAMP_ADD(4);                                                        // W store-out
         }
@@ -335,7 +365,7 @@ __device__ __forceinline__ void slab_body(const SlabArgs& A) {
         float2* __restrict__ psb = (float2*)out.pilot_symbols + (size_t)b * out.pilot_stride;
         const bool al = (((uintptr_t)psb) & 15) == 0;
         for (int i = 2 * tid; i < P; i += 2 * (int)blockDim.x) {
-            float2 xs[2];
+            float2 xs2[2];
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int p = i + j < P ? i + j : P - 1;
@@ -348,10 +378,10 @@ __device__ __forceinline__ void slab_body(const SlabArgs& A) {
                     const u32x4 z = draw(A.key, STREAM_SYM, (uint32_t)(sy * npair + (k >> 1)));
                     u = u01((k & 1) ? z.y : z.x);
                 }
-                xs[j] = cis_unit(__builtin_amdgcn_fractf(u));
+                xs2[j] = cis_unit(__builtin_amdgcn_fractf(u));
             }
-            if (al && i + 1 < P) st16(psb + i, make_float4(xs[0].x, xs[0].y, xs[1].x, xs[1].y));
-            else { st8(psb + i, xs[0]); if (i + 1 < P) st8(psb + i + 1, xs[1]); }
+            if (al && i + 1 < P) st16(psb + i, make_float4(xs2[0].x, xs2[0].y, xs2[1].x, xs2[1].y));
+            else { st8(psb + i, xs2[0]); if (i + 1 < P) st8(psb + i + 1, xs2[1]); }
         }
     }
     if (out.h_ls_pilots != nullptr) {                // LS estimates at the pilots, [R][stride] per frame, zero padded
@@ -379,51 +409,68 @@ __device__ __forceinline__ void slab_body(const SlabArgs& A) {
     //      assembled in the slab and streamed out; optional error sums. -----------------------------------------------
     const PlanRec* __restrict__ plan = (const PlanRec*)pat.plan;
     const float invT = 1.0f / (float)T;
-    const int seg_l = 0, seg_m = slab_seg(RG * T, nsc);
+    const int seg_l = 0, seg_m = slab_seg(SSN * RG * T, nsc);
     float m_ls = 0.f, m_mm = 0.f;
-    PlanRec c0n = plan[kc0], c1n = plan[kc1];
+    PlanRec cn[SSN][2];                                                          // plan records, one unit ahead
+#pragma unroll
+    for (int ss = 0; ss < SSN; ++ss) {
+        const int sy = ss < S ? ss : S - 1;
+        cn[ss][0] = plan[sy * nsc + kc0]; cn[ss][1] = plan[sy * nsc + kc1];
+    }
     first_unit = true;
     STAMP_ADD(6);                                                                // pilot outputs + alpha
-    for (int s = 0; s < S; ++s) {
-        const PlanRec c0 = c0n, c1 = c1n;
-        if (s + 1 < S) { c0n = plan[(s + 1) * nsc + kc0]; c1n = plan[(s + 1) * nsc + kc1]; }
+    for (int sb = 0; sb < S; sb += SSN) {
+        const int ns = SSN == 1 ? 1 : min(SSN, S - sb);
+        PlanRec cc[SSN][2];
+#pragma unroll
+        for (int ss = 0; ss < SSN; ++ss) {
+            cc[ss][0] = cn[ss][0]; cc[ss][1] = cn[ss][1];
+            const int sn = sb + SSN + ss;
+            if (sn < S) { cn[ss][0] = plan[sn * nsc + kc0]; cn[ss][1] = plan[sn * nsc + kc1]; }
+        }
         for (int rg = 0; rg < ngroups; ++rg) {
             const int r0 = rg * RG;
-            const unsigned e_h = (unsigned)((s * R + r0) * T) * (unsigned)nsc;
+            const unsigned e_h = (unsigned)((sb * R + r0) * T) * (unsigned)nsc;
             float2* __restrict__ l_l = slab + seg_l + ((par_h + e_h) & 1);
             float2* __restrict__ l_m = slab + seg_m + ((par_h + e_h) & 1);
             // the unit's estimates first (registers; reads hp only), then the slab hand-over
-            float2 ev[STAGED ? RGT : 1][2];
+            float2 ev[SSN][STAGED ? RGT : 1][2];
             if constexpr (STAGED) {
 #pragma unroll
-                for (int rr = 0; rr < RGT; ++rr) { ev[rr][0] = interp(c0, hp, R, r0 + rr); ev[rr][1] = interp(c1, hp, R, r0 + rr); }
+                for (int ss = 0; ss < SSN; ++ss)
+#pragma unroll
+                    for (int rr = 0; rr < RGT; ++rr) { ev[ss][rr][0] = interp(cc[ss][0], hp, R, r0 + rr); ev[ss][rr][1] = interp(cc[ss][1], hp, R, r0 + rr); }
             }
             if (want_metrics) {
                 // sum_t |H_t - v|^2 = sum_t |H_t - Hbar|^2 + T |Hbar - v|^2 ; the first term is
                 // estimate-independent and comes analytically from K1 (ST_SUM_VAR).
-                for (int rr = 0; rr < RG; ++rr) {
-                    const int r = r0 + rr;
-                    const float al = A.alpha[r];
-                    float2 e0, e1;
-                    if constexpr (STAGED) { e0 = ev[rr][0]; e1 = ev[rr][1]; }
-                    else { e0 = interp(c0, hp, R, r); e1 = interp(c1, hp, R, r); }
-                    const float2* __restrict__ coef = A.csum_g + (size_t)s * KTS * R + r;      // tap d at stride R
-                    float2 hb0 = make_float2(0.f, 0.f), hb1 = make_float2(0.f, 0.f);
 #pragma unroll
-                    for (int d = 0; d < NT; ++d) {
-                        const float2 c = coef[d * R];
-                        cfma(hb0, c, w[d][0]);
-                        cfma(hb1, c, w_odd(d));
-                    }
-                    if (act) {
-                        const float2 m = make_float2(hb0.x * invT, hb0.y * invT), f = make_float2(al * e0.x, al * e0.y);
-                        m_ls += cabs2(make_float2(m.x - e0.x, m.y - e0.y));
-                        m_mm += cabs2(make_float2(m.x - f.x, m.y - f.y));
-                    }
-                    if (v1) {
-                        const float2 m = make_float2(hb1.x * invT, hb1.y * invT), f = make_float2(al * e1.x, al * e1.y);
-                        m_ls += cabs2(make_float2(m.x - e1.x, m.y - e1.y));
-                        m_mm += cabs2(make_float2(m.x - f.x, m.y - f.y));
+                for (int ss = 0; ss < SSN; ++ss) {
+                    if (ss >= ns) continue;
+                    for (int rr = 0; rr < RG; ++rr) {
+                        const int r = r0 + rr;
+                        const float al = A.alpha[r];
+                        float2 e0, e1;
+                        if constexpr (STAGED) { e0 = ev[ss][rr][0]; e1 = ev[ss][rr][1]; }
+                        else { e0 = interp(cc[ss][0], hp, R, r); e1 = interp(cc[ss][1], hp, R, r); }
+                        const float2* __restrict__ coef = A.csum_g + (size_t)(sb + ss) * KTS * R + r;      // tap d at stride R
+                        float2 hb0 = make_float2(0.f, 0.f), hb1 = make_float2(0.f, 0.f);
+#pragma unroll
+                        for (int d = 0; d < NT; ++d) {
+                            const float2 c = coef[d * R];
+                            cfma(hb0, c, w[d][0]);
+                            cfma(hb1, c, w_odd(d));
+                        }
+                        if (act) {
+                            const float2 m = make_float2(hb0.x * invT, hb0.y * invT), f = make_float2(al * e0.x, al * e0.y);
+                            m_ls += cabs2(make_float2(m.x - e0.x, m.y - e0.y));
+                            m_mm += cabs2(make_float2(m.x - f.x, m.y - f.y));
+                        }
+                        if (v1) {
+                            const float2 m = make_float2(hb1.x * invT, hb1.y * invT), f = make_float2(al * e1.x, al * e1.y);
+                            m_ls += cabs2(make_float2(m.x - e1.x, m.y - e1.y));
+                            m_mm += cabs2(make_float2(m.x - f.x, m.y - f.y));
+                        }
                     }
                 }
             }
@@ -433,17 +480,21 @@ __device__ __forceinline__ void slab_body(const SlabArgs& A) {
             first_unit = false;
             STAMP_ADD(8);                                                        // E barrier B
             if (act) {
-                for (int rr = 0; rr < RG; ++rr) {
-                    const int r = r0 + rr;
-                    const float al = A.alpha[r];
-                    float2 e0, e1;
-                    if constexpr (STAGED) { e0 = ev[rr][0]; e1 = ev[rr][1]; }
-                    else { e0 = interp(c0, hp, R, r); e1 = interp(c1, hp, R, r); }
-                    const float2 f0 = make_float2(al * e0.x, al * e0.y), f1 = make_float2(al * e1.x, al * e1.y);
-                    for (int t = 0; t < T; ++t) {
-                        const int row = (rr * T + t) * nsc;
-                        if (Lb != nullptr) put(l_l + row, e0, e1);
-                        if (Mb != nullptr) put(l_m + row, f0, f1);
+#pragma unroll
+                for (int ss = 0; ss < SSN; ++ss) {
+                    if (ss >= ns) continue;
+                    for (int rr = 0; rr < RG; ++rr) {
+                        const int r = r0 + rr;
+                        const float al = A.alpha[r];
+                        float2 e0, e1;
+                        if constexpr (STAGED) { e0 = ev[ss][rr][0]; e1 = ev[ss][rr][1]; }
+                        else { e0 = interp(cc[ss][0], hp, R, r); e1 = interp(cc[ss][1], hp, R, r); }
+                        const float2 f0 = make_float2(al * e0.x, al * e0.y), f1 = make_float2(al * e1.x, al * e1.y);
+                        for (int t = 0; t < T; ++t) {
+                            const int row = ((ss * RG + rr) * T + t) * nsc;
+                            if (Lb != nullptr) put(l_l + row, e0, e1);
+                            if (Mb != nullptr) put(l_m + row, f0, f1);
+                        }
                     }
                 }
             }
@@ -452,8 +503,8 @@ __device__ __forceinline__ void slab_body(const SlabArgs& A) {
             STAMP_ADD(10);                                                       // E barrier A
             if (storer) {
                 int ph = wave;
-                if (Lb != nullptr) { const int n = seg_store(Lb + e_h, l_l, RG * T * nsc, ph, nstw, lane); ph = (ph + nstw - n % nstw) % nstw; }
-                if (Mb != nullptr) seg_store(Mb + e_h, l_m, RG * T * nsc, ph, nstw, lane);
+                if (Lb != nullptr) { const int n = seg_store(Lb + e_h, l_l, ns * RG * T * nsc, ph, nstw, lane); ph = (ph + nstw - n % nstw) % nstw; }
+                if (Mb != nullptr) seg_store(Mb + e_h, l_m, ns * RG * T * nsc, ph, nstw, lane);
             }
             STAMP_ADD(11);                                                       // E store-out
         }
@@ -481,7 +532,7 @@ __device__ __forceinline__ void slab_body(const SlabArgs& A) {
 }
 
 // MAXTHR: largest workgroup this instantiation is launched with (320 = 5 waves covers nsc <= 640, the 1024-FFT grids).
-template <int MAXTHR, int MINW, int TT, int RR, int RGT, bool INJ>
+template <int MAXTHR, int MINW, int TT, int RR, int RGT, int SS, bool INJ>
 __global__ void __launch_bounds__(MAXTHR, MINW)
 frame_slab_kernel(const FrameParams* __restrict__ fpp, const chest_frame_desc* __restrict__ descs,
                   const PatternDev* __restrict__ patterns, int Pmax, uint64_t seed, uint64_t frame_offset,
@@ -563,9 +614,9 @@ frame_slab_kernel(const FrameParams* __restrict__ fpp, const chest_frame_desc* _
     A.key = RngKey{(uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)frame, (uint32_t)(frame >> 32)};
     A.b = b; A.RG = RG;
     switch (A.prof->ntaps) {                                     // workgroup-uniform dispatch on the profile
-        case 5: slab_body<5, TT, RR, RGT, INJ>(A); break;             // EPA at 15.36 MHz
-        case 8: slab_body<8, TT, RR, RGT, INJ>(A); break;             // EVA
-        default: slab_body<KT, TT, RR, RGT, INJ>(A); break;           // ETU / anything else (taps padded with zeros)
+        case 5: slab_body<5, TT, RR, RGT, SS, INJ>(A); break;             // EPA at 15.36 MHz
+        case 8: slab_body<8, TT, RR, RGT, SS, INJ>(A); break;             // EVA
+        default: slab_body<KT, TT, RR, RGT, SS, INJ>(A); break;           // ETU / anything else (taps padded with zeros)
     }
 #ifdef CHEST_STAMPS
     if (g_stamp_buf != nullptr && (tid & 63) == 0) {
@@ -580,8 +631,8 @@ frame_slab_kernel(const FrameParams* __restrict__ fpp, const chest_frame_desc* _
 #endif
 }
 
-size_t slab_lds_bytes(int nsc, int T, int R, int RG, int Pmax) {
-    return ((((size_t)Pmax * R + 1) & ~(size_t)1) + (size_t)slab_elems(T, RG, nsc)) * sizeof(float2) + 40 * sizeof(float);
+size_t slab_lds_bytes(int nsc, int T, int R, int RG, int Pmax, int SS) {
+    return ((((size_t)Pmax * R + 1) & ~(size_t)1) + (size_t)slab_elems(T, RG, nsc, SS)) * sizeof(float2) + 40 * sizeof(float);
 }
 
 // Rx antennas per unit: the largest divisor of R whose slab still lets two workgroups share a CU's 160 KiB of LDS (long
@@ -594,19 +645,19 @@ static int choose_rx_group(const chest_ctx* ctx, int Pmax) {
     int best2 = 0, best1 = 1;
     for (int rg = 1; rg <= fp.R; ++rg) {
         if (fp.R % rg) continue;
-        const size_t lds = slab_lds_bytes(fp.nsc, fp.T, fp.R, rg, Pmax);
+        const size_t lds = slab_lds_bytes(fp.nsc, fp.T, fp.R, rg, Pmax, 1);
         if (lds <= 80 * 1024) best2 = rg;
         if (lds <= 160 * 1024) best1 = rg;
     }
     return best2 ? best2 : best1;
 }
 
-template <int MAXTHR, int MINW, int TT, int RR, int RGT, bool INJ>
+template <int MAXTHR, int MINW, int TT, int RR, int RGT, int SS, bool INJ>
 static int launch_one(chest_ctx* ctx, int which, hipStream_t st, dim3 grid, dim3 block, size_t lds, const chest_frame_desc* descs, int Pmax,
                       uint64_t seed, uint64_t frame_offset, const chest_injected& inj, const chest_frame_outputs& out,
                       const float* workspace, int RG) {
-    CHEST_LDS_OPT_IN(ctx, which, (frame_slab_kernel<MAXTHR, MINW, TT, RR, RGT, INJ>), lds);
-    hipLaunchKernelGGL((frame_slab_kernel<MAXTHR, MINW, TT, RR, RGT, INJ>), grid, block, lds, st, ctx->d_fp, descs, ctx->d_patterns, Pmax,
+    CHEST_LDS_OPT_IN(ctx, which, (frame_slab_kernel<MAXTHR, MINW, TT, RR, RGT, SS, INJ>), lds);
+    hipLaunchKernelGGL((frame_slab_kernel<MAXTHR, MINW, TT, RR, RGT, SS, INJ>), grid, block, lds, st, ctx->d_fp, descs, ctx->d_patterns, Pmax,
                        seed, frame_offset, inj, out, workspace, RG, ctx->d_status);
     return CHEST_OK;
 }
@@ -617,30 +668,37 @@ int launch_k2_slab(chest_ctx* ctx, hipStream_t st, int32_t B, const chest_frame_
     const int npair = (fp.nsc + 1) / 2, nwave = (npair + 63) / 64;
     if (nwave > 16) { set_error("frame kernel handles at most 2047 used subcarriers (got %d)", fp.nsc); return CHEST_EINVAL; }
     const int RG = choose_rx_group(ctx, Pmax);
-    const size_t lds = slab_lds_bytes(fp.nsc, fp.T, fp.R, RG, Pmax);
+    const int T = fp.T, R = fp.R;
+    const bool injected = inj.u_sym || inj.u_angle || inj.n_re;         // parity / replay mode: the generic instantiations
+    // SISO frames have three rows per symbol: two symbols per unit halve the per-unit synchronisation (the spans of
+    // consecutive symbols are contiguous when a unit holds all rx antennas)
+#ifndef CHEST_SS_SISO
+#define CHEST_SS_SISO 2
+#endif
+    constexpr int SS_SISO = CHEST_SS_SISO;
+    const bool siso = !injected && !(fp.half & 1) && nwave <= 5 && T == 1 && R == 1 && RG == 1;
+    const size_t lds = slab_lds_bytes(fp.nsc, fp.T, fp.R, RG, Pmax, siso ? SS_SISO : 1);
     if (lds > 160 * 1024) { set_error("frame kernel needs %zu B of LDS (> 160 KiB): too many antennas, subcarriers or pilots", lds); return CHEST_EINVAL; }
     const dim3 grid((unsigned)B), block((unsigned)nwave * 64);
-    const int T = fp.T, R = fp.R;
 #define CHEST_SLAB_ARGS st, grid, block, lds, descs, Pmax, seed, frame_offset, inj, out, workspace, RG
-    const bool injected = inj.u_sym || inj.u_angle || inj.n_re;         // parity / replay mode: the generic instantiations
     if (nwave <= 5) {                      // the 1024-FFT grids (nsc <= 640): specialised antenna counts on the device-RNG path
         if (!injected) {
-            if (fp.half & 1) return launch_one<320, 4, 0, 0, 0, true>(ctx, LDS_FRAME_GEN, CHEST_SLAB_ARGS);   // a pair straddles DC
+            if (fp.half & 1) return launch_one<320, 4, 0, 0, 0, 1, true>(ctx, LDS_FRAME_GEN, CHEST_SLAB_ARGS);   // a pair straddles DC
             // 2x2: 96 VGPRs (five waves per SIMD) so that THREE 5-wave workgroups are resident per CU -- at 128 VGPRs only two
             // are placed although 15 waves would fit; 2.00 against 2.33 ms per 10 000 frames (chest_tune "frame_min_waves" = 4
             // selects the 128-VGPR instantiation for A/B)
-            if (T == 2 && R == 2 && RG == 2 && ctx->tune_min_waves == 4) return launch_one<320, 4, 2, 2, 2, false>(ctx, LDS_FRAME_W5, CHEST_SLAB_ARGS);
-            if (T == 2 && R == 2 && RG == 2) return launch_one<320, 5, 2, 2, 2, false>(ctx, LDS_FRAME, CHEST_SLAB_ARGS);
-            if (T == 4 && R == 4 && RG == 1) return launch_one<320, 4, 4, 4, 1, false>(ctx, LDS_FRAME_44, CHEST_SLAB_ARGS);
-            if (T == 1 && R == 1 && RG == 1) return launch_one<320, 5, 1, 1, 1, false>(ctx, LDS_FRAME_11, CHEST_SLAB_ARGS);
+            if (T == 2 && R == 2 && RG == 2 && ctx->tune_min_waves == 4) return launch_one<320, 4, 2, 2, 2, 1, false>(ctx, LDS_FRAME_W5, CHEST_SLAB_ARGS);
+            if (T == 2 && R == 2 && RG == 2) return launch_one<320, 5, 2, 2, 2, 1, false>(ctx, LDS_FRAME, CHEST_SLAB_ARGS);
+            if (T == 4 && R == 4 && RG == 1) return launch_one<320, 4, 4, 4, 1, 1, false>(ctx, LDS_FRAME_44, CHEST_SLAB_ARGS);
+            if (siso) return launch_one<320, 5, 1, 1, 1, SS_SISO, false>(ctx, LDS_FRAME_11, CHEST_SLAB_ARGS);
         }
-        return launch_one<320, 4, 0, 0, 0, true>(ctx, LDS_FRAME_GEN, CHEST_SLAB_ARGS);
+        return launch_one<320, 4, 0, 0, 0, 1, true>(ctx, LDS_FRAME_GEN, CHEST_SLAB_ARGS);
     }
     if (nwave <= 10) {                     // the 2048-FFT grids (nsc <= 1280)
-        if (!injected && !(fp.half & 1) && T == 4 && R == 4 && RG == 1) return launch_one<640, 3, 4, 4, 1, false>(ctx, LDS_FRAME_640_44, CHEST_SLAB_ARGS);
-        return launch_one<640, 3, 0, 0, 0, true>(ctx, LDS_FRAME_640, CHEST_SLAB_ARGS);
+        if (!injected && !(fp.half & 1) && T == 4 && R == 4 && RG == 1) return launch_one<640, 3, 4, 4, 1, 1, false>(ctx, LDS_FRAME_640_44, CHEST_SLAB_ARGS);
+        return launch_one<640, 3, 0, 0, 0, 1, true>(ctx, LDS_FRAME_640, CHEST_SLAB_ARGS);
     }
-    return launch_one<1024, 4, 0, 0, 0, true>(ctx, LDS_FRAME_1024, CHEST_SLAB_ARGS);
+    return launch_one<1024, 4, 0, 0, 0, 1, true>(ctx, LDS_FRAME_1024, CHEST_SLAB_ARGS);
 #undef CHEST_SLAB_ARGS
 }
 
