@@ -50,7 +50,8 @@ def test_config5_shape_4x4_2048fft():
 
 
 @pytest.mark.parametrize("S,T,R,U,ct", [(7, 1, 2, 72, "EPA"), (3, 3, 3, 300, "EVA"), (14, 2, 1, 128, "ETU"),
-                                         (20, 2, 2, 254, "EPA"), (14, 8, 8, 72, "EVA")])
+                                         (20, 2, 2, 254, "EPA"), (14, 8, 8, 72, "EVA"),
+                                         (7, 1, 1, 600, "EPA"), (5, 1, 1, 72, "ETU")])   # SISO: two-symbol units, ragged last unit
 def test_unusual_symbol_and_antenna_counts(S, T, R, U, ct):
     _check_native(E.Geometry(num_symbols=S, useful_subcarriers=U, num_tx=T, num_rx=R), ct, 123.4, 7.0, 0.10)
 
