@@ -101,9 +101,9 @@ size_t pattern_build_lds_bytes(int G, int Pcap) {
 }
 
 #ifdef CHEST_STAMPS
-__device__ unsigned long long* g_pat_stamp = nullptr;           // [count][8] cycles of wave 0 per phase (diagnostic build only)
+__device__ unsigned long long* g_pat_stamp = nullptr;           // [count][16]: cycles of wave 0 per phase, then detail slots (diagnostic build only)
 #define PSTAMP(i) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
-                       if (tid == 0 && g_pat_stamp) g_pat_stamp[(size_t)blockIdx.x * 8 + (i)] = now_ - pst_; pst_ = now_; \
+                       if (tid == 0 && g_pat_stamp) g_pat_stamp[(size_t)blockIdx.x * 16 + (i)] = now_ - pst_; pst_ = now_; \
                        __builtin_amdgcn_sched_barrier(0); } while (0)
 #else
 #define PSTAMP(i) do { } while (0)
@@ -394,7 +394,17 @@ pattern_build_kernel(const PatBuildArgs A) {
     uint32_t active = 0;
     for (int i = 0, t = tid; t < ntri; t += PB_THREADS, ++i) { claim[t] = CLAIM_DIRTY; partner[t] = (uint16_t)TNONE; active |= 1u << i; }
     __syncthreads();
+#ifdef CHEST_STAMPS
+    unsigned dbg_rounds = 0, dbg_cross = 0;
+    unsigned long long dbg_ph[4] = {0, 0, 0, 0}, dbg_t = __builtin_amdgcn_s_memtime();
+#define DBG_PH(i) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); dbg_ph[i] += n_ - dbg_t; dbg_t = n_; } while (0)
+#else
+#define DBG_PH(i) do { } while (0)
+#endif
     for (int round = 0; round < 4 * NT + 64; ++round) {
+#ifdef CHEST_STAMPS
+        ++dbg_rounds;
+#endif
         if (tid == 0) cnt_s[3] = 0;
         __syncthreads();
         // phase 0: active triangles test their edges; an edge that fails the in-circle test claims both of its triangles
@@ -418,6 +428,7 @@ pattern_build_kernel(const PatBuildArgs A) {
             }
         }
         __syncthreads();
+        DBG_PH(0);
         if (cnt_s[3] == 0) break;
         // phase 1: winners (an edge that holds the claim on both of its triangles) rewrite the two triangles; outer neighbours
         // keep their OLD ids for now
@@ -442,6 +453,7 @@ pattern_build_kernel(const PatBuildArgs A) {
             partner[t] = (uint16_t)u; partner[u] = (uint16_t)t;
         }
         __syncthreads();
+        DBG_PH(1);
         // phase 2: the owner of every flip resolves the outer neighbours of its two new triangles (the old neighbour, or its
         // partner if that one flipped too) and writes the back-pointer of neighbours that did not flip
         for (uint32_t m = active; m != 0; m &= m - 1) {
@@ -472,6 +484,7 @@ pattern_build_kernel(const PatBuildArgs A) {
             }
         }
         __syncthreads();
+        DBG_PH(2);
         // claimed triangles (flipped, or candidates that lost) are the next round's active set; marks that drew no claim clear
         active = 0;
         for (int i = 0, t = tid; t < ntri; t += PB_THREADS, ++i) {
@@ -483,6 +496,7 @@ pattern_build_kernel(const PatBuildArgs A) {
             if (act) active |= 1u << i;
         }
         __syncthreads();
+        DBG_PH(3);
     }
 
     PSTAMP(5);                                                   // flips
@@ -505,9 +519,31 @@ pattern_build_kernel(const PatBuildArgs A) {
     // element).  While the triangle stays the same the three edge functions are updated incrementally (they are affine in
     // the column); they are recomputed only after a crossing.
     if (ntri > 0) {
+        // Start of a walk: a triangle incident to the pilot nearest (in element order: the one before or the one after, whichever
+        // is closer in the plane) to the element.  After the flips triangle numbers say nothing about position, and a walk
+        // from a far triangle crosses hundreds of them along the 599-column axis (stamps: 407 crossings for 33 elements).
+        // (the smallest incident triangle number, so that a rebuilt pattern gives the bit-identical plan: an element ON an
+        // edge belongs to whichever of the two triangles the walk reaches first)
+        uint32_t* __restrict__ v2t = (uint32_t*)partner;         // partner[] (2 * Pcap uint16) is free after the flips
+        for (int i = tid; i < P; i += PB_THREADS) v2t[i] = 0xFFFFFFFFu;
+        __syncthreads();
+        for (int t = tid; t < ntri; t += PB_THREADS) { atomicMin(&v2t[tv0[t]], (uint32_t)t); atomicMin(&v2t[tv1[t]], (uint32_t)t); atomicMin(&v2t[tv2[t]], (uint32_t)t); }
+        __syncthreads();
+        auto near_tri = [&](int s_, int k_) -> int {
+            const uint32_t q = ((uint32_t)s_ << 16) | (uint32_t)k_;
+            int ip = count_less(pts, P, q);                      // first pilot at or after the element
+            if (ip >= P) ip = P - 1;
+            if (ip > 0) {
+                const uint32_t a = pts[ip - 1], b = pts[ip];
+                const int da = (s_ - px_of(a)) * (s_ - px_of(a)) + (k_ - py_of(a)) * (k_ - py_of(a));
+                const int db = (s_ - px_of(b)) * (s_ - px_of(b)) + (k_ - py_of(b)) * (k_ - py_of(b));
+                if (da < db) --ip;
+            }
+            return (int)v2t[ip];
+        };
         int g = g_lo;
         int s = g / nsc, k = g - s * nsc;
-        int t = (int)(((long long)g_lo * ntri) / (G > 0 ? G : 1));                     // strips are laid out in element order
+        int t = g < g_hi ? near_tri(s, k) : 0;
         uint32_t i0 = 0, i1 = 0, i2 = 0;
         int o0 = 0, o1 = 0, o2 = 0, d0 = 0, d1 = 0, d2 = 0;
         bool fresh = true;                                        // triangle t not loaded yet
@@ -525,6 +561,9 @@ pattern_build_kernel(const PatBuildArgs A) {
             if (o0 < 0) { nx = tn0[t]; cross = true; }
             else if (o1 < 0) { nx = tn1[t]; cross = true; }
             else if (o2 < 0) { nx = tn2[t]; cross = true; }
+#ifdef CHEST_STAMPS
+            if (cross && nx != TNONE) ++dbg_cross;
+#endif
             if (cross && nx != TNONE && since <= ntri + 8) { t = (int)nx; fresh = true; ++since; continue; }
             PlanRec rec{0.f, 0.f, 0u, 0u};                        // leaving through a hull edge: outside the convex hull
             if (!cross) {
@@ -549,7 +588,7 @@ pattern_build_kernel(const PatBuildArgs A) {
             ++g; since = 0;
             if (++k == nsc) {                                     // next row: far from here, start again from the layout guess
                 k = 0; ++s;
-                t = (int)(((long long)g * ntri) / G);
+                if (g < g_hi) t = near_tri(s, k);
                 fresh = true;
             } else { o0 += d0; o1 += d1; o2 += d2; }
         }
@@ -557,6 +596,16 @@ pattern_build_kernel(const PatBuildArgs A) {
         for (int g = g_lo; g < g_hi; ++g) plan[g] = PlanRec{0.f, 0.f, 0u, 0u};
     }
     PSTAMP(6);                                                   // plan walk
+#ifdef CHEST_STAMPS
+    if (g_pat_stamp) {                                           // slot 7: flip rounds | largest crossing count of a lane of wave 0 << 32
+        for (int off = 32; off > 0; off >>= 1) { const unsigned o = __shfl_xor(dbg_cross, off, 64); dbg_cross = o > dbg_cross ? o : dbg_cross; }
+        if (tid == 0) {
+            unsigned long long* d_ = g_pat_stamp + (size_t)blockIdx.x * 16;
+            d_[7] = (unsigned long long)dbg_rounds | ((unsigned long long)dbg_cross << 32);
+            for (int i_ = 0; i_ < 4; ++i_) d_[8 + i_] = dbg_ph[i_];
+        }
+    }
+#endif
 }
 
 }  // namespace chest

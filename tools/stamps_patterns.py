@@ -20,7 +20,7 @@ def main():
     N = importlib.import_module(PKG + "._native")
     n = 4096
     eng = E.Engine(E.Geometry(), 0)
-    buf = torch.zeros(n * 8, dtype=torch.int64, device=eng.device)
+    buf = torch.zeros(n * 16, dtype=torch.int64, device=eng.device)
     lib = N.lib()
     lib.chest_debug_set_pattern_stamp_buffer.argtypes = [ctypes.c_void_p]
     assert lib.chest_debug_set_pattern_stamp_buffer(buf.data_ptr()) == 0
@@ -28,7 +28,11 @@ def main():
         for _ in range(2):
             eng.build_patterns(P * 10, [P] * n, seed=1, pattern_ids=np.arange(n, dtype=np.uint64), method="linear")
         torch.cuda.synchronize()
-        st = buf.cpu().numpy().reshape(n, 8)[:, :7].astype(np.float64)
+        raw = buf.cpu().numpy().reshape(n, 16)
+        st = raw[:, :7].astype(np.float64)
+        rounds, cross = raw[:, 7] & 0xFFFFFFFF, raw[:, 7] >> 32
+        print(f"P = {P}: flip phases (cycles per pattern, wave 0): test {raw[:, 8].mean():,.0f}  rewrite {raw[:, 9].mean():,.0f}  relink {raw[:, 10].mean():,.0f}  next active set {raw[:, 11].mean():,.0f}")
+        print(f"P = {P}: flip rounds mean {rounds.mean():.1f} max {rounds.max()}; walk: most crossings by one lane of wave 0: mean {cross.mean():.0f} max {cross.max()}")
         print(f"P = {P}: total {st.sum(1).mean():,.0f} cycles per pattern")
         for i, nm in enumerate(NAMES):
             print(f"   {nm:16s} {st[:, i].mean():10,.0f}  {st[:, i].sum() / st.sum():6.1%}")
