@@ -21,6 +21,14 @@
 
 namespace chest {
 
+// Pointers read out of the pattern table are generic to the compiler and would be dereferenced with FLAT instructions, which
+// count against the LDS / scalar-load counter as well (a wait for an LDS read then also waits for the outstanding prefetch from
+// HBM).  They always point to device memory: say so.
+#define CHEST_GLOBAL __attribute__((address_space(1)))
+typedef const CHEST_GLOBAL uint16_t* gptr_u16;
+typedef const CHEST_GLOBAL int32_t* gptr_i32;
+typedef uint32_t v4u_t __attribute__((ext_vector_type(4)));
+typedef const CHEST_GLOBAL v4u_t* gptr_plan;
 typedef float v4f_t __attribute__((ext_vector_type(4)));
 typedef float v2f_t __attribute__((ext_vector_type(2)));
 
@@ -32,6 +40,11 @@ __device__ __forceinline__ void st16(float2* p, float4 v) {
 __device__ __forceinline__ void st8(float2* p, float2 a) {
     const v2f_t t = {a.x, a.y};
     __builtin_nontemporal_store(t, (v2f_t*)p);
+}
+
+__device__ __forceinline__ PlanRec ld_plan(gptr_plan plan, int i) {     // one 16-B global load
+    const v4u_t v = plan[i];
+    return PlanRec{__uint_as_float(v.x), __uint_as_float(v.y), v.z, v.w};
 }
 
 // Copy LDS segment l[0..n) to global g[0..n) (float2 elements; g and l wave-uniform with equal address mod 16).
@@ -137,7 +150,7 @@ __device__ __forceinline__ void slab_body(const SlabArgs& A) {
     const float* __restrict__ usym = (INJ && inj.u_sym) ? inj.u_sym + (size_t)b * G : nullptr;
     const float* __restrict__ nre = (INJ && inj.n_re) ? inj.n_re + (size_t)b * S * R * nsc : nullptr;
     const float* __restrict__ nim = (INJ && inj.n_im) ? inj.n_im + (size_t)b * S * R * nsc : nullptr;
-    const uint16_t* __restrict__ slots = pat.slot;
+    const gptr_u16 slots = (gptr_u16)pat.slot;
     // parity (element offset & 1) of the frame's first element in each tensor; 16-B-aligned tensor bases (host-checked)
     const int par_tx = (int)(((size_t)b * S * T * nsc) & 1), par_rx = (int)(((size_t)b * S * R * nsc) & 1),
               par_h = (int)(((size_t)b * S * R * T * nsc) & 1);
@@ -373,7 +386,7 @@ __device__ __forceinline__ void slab_body(const SlabArgs& A) {
                 if (usym != nullptr) {
                     u = usym[p];                                                 // first P draws are the pilot phases (:395)
                 } else {
-                    const int g = pat.pilot_idx[p];
+                    const int g = ((gptr_i32)pat.pilot_idx)[p];
                     const int sy = g / nsc, k = g - sy * nsc;
                     const u32x4 z = draw(A.key, STREAM_SYM, (uint32_t)(sy * npair + (k >> 1)));
                     u = u01((k & 1) ? z.y : z.x);
@@ -407,7 +420,7 @@ __device__ __forceinline__ void slab_body(const SlabArgs& A) {
 
     // ---- phase E: plan-driven interpolation (griddata linear/nearest as a 3-point gather), tx-replicated rows (quirk Q9)
     //      assembled in the slab and streamed out; optional error sums. -----------------------------------------------
-    const PlanRec* __restrict__ plan = (const PlanRec*)pat.plan;
+    const gptr_plan plan = (gptr_plan)pat.plan;
     const float invT = 1.0f / (float)T;
     const int seg_l = 0, seg_m = slab_seg(SSN * RG * T, nsc);
     float m_ls = 0.f, m_mm = 0.f;
@@ -415,7 +428,7 @@ __device__ __forceinline__ void slab_body(const SlabArgs& A) {
 #pragma unroll
     for (int ss = 0; ss < SSN; ++ss) {
         const int sy = ss < S ? ss : S - 1;
-        cn[ss][0] = plan[sy * nsc + kc0]; cn[ss][1] = plan[sy * nsc + kc1];
+        cn[ss][0] = ld_plan(plan, sy * nsc + kc0); cn[ss][1] = ld_plan(plan, sy * nsc + kc1);
     }
     first_unit = true;
     STAMP_ADD(6);                                                                // pilot outputs + alpha
@@ -426,7 +439,7 @@ __device__ __forceinline__ void slab_body(const SlabArgs& A) {
         for (int ss = 0; ss < SSN; ++ss) {
             cc[ss][0] = cn[ss][0]; cc[ss][1] = cn[ss][1];
             const int sn = sb + SSN + ss;
-            if (sn < S) { cn[ss][0] = plan[sn * nsc + kc0]; cn[ss][1] = plan[sn * nsc + kc1]; }
+            if (sn < S) { cn[ss][0] = ld_plan(plan, sn * nsc + kc0); cn[ss][1] = ld_plan(plan, sn * nsc + kc1); }
         }
         for (int rg = 0; rg < ngroups; ++rg) {
             const int r0 = rg * RG;
@@ -569,13 +582,14 @@ frame_slab_kernel(const FrameParams* __restrict__ fpp, const chest_frame_desc* _
 
     // ---- pilot mask: 16 resource elements per thread and one 16-B store, after peeling the row to 16-B alignment
     //      (G is rarely a multiple of 16, so most rows start misaligned) ---------------------------------------------
+    const gptr_u16 gslot = (gptr_u16)pat.slot;
     if (out.pilot_mask != nullptr) {
         uint8_t* mrow = out.pilot_mask + (size_t)b * G;
         const int lead = min(G, (int)((16 - ((uintptr_t)mrow & 15)) & 15));
         const int nvec = (G - lead) >> 4, tail0 = lead + (nvec << 4);
-        if (tid < lead) mrow[tid] = pat.slot[tid] < P ? 1 : 0;
+        if (tid < lead) mrow[tid] = gslot[tid] < P ? 1 : 0;
         for (int v = tid; v < nvec; v += blockDim.x) {
-            const uint16_t* sp = pat.slot + lead + (v << 4);
+            const gptr_u16 sp = gslot + lead + (v << 4);
             uint32_t wq[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -585,20 +599,20 @@ frame_slab_kernel(const FrameParams* __restrict__ fpp, const chest_frame_desc* _
             }
             *(uint4*)(mrow + lead + (v << 4)) = make_uint4(wq[0], wq[1], wq[2], wq[3]);
         }
-        if (tid < G - tail0) mrow[tail0 + tid] = pat.slot[tail0 + tid] < P ? 1 : 0;
+        if (tid < G - tail0) mrow[tail0 + tid] = gslot[tail0 + tid] < P ? 1 : 0;
     }
     // the same mask as float32 0/1 (the dataset schema of run_phase3_dataset_generation.py:139): 4 elements per 16-B store
     if (out.pilot_mask_f32 != nullptr) {
         float* mrow = out.pilot_mask_f32 + (size_t)b * G;
         const int lead = min(G, (int)(((16 - ((uintptr_t)mrow & 15)) & 15) >> 2));
         const int nvec = (G - lead) >> 2, tail0 = lead + (nvec << 2);
-        if (tid < lead) mrow[tid] = pat.slot[tid] < P ? 1.f : 0.f;
+        if (tid < lead) mrow[tid] = gslot[tid] < P ? 1.f : 0.f;
         for (int v = tid; v < nvec; v += blockDim.x) {
-            const uint16_t* sp = pat.slot + lead + (v << 2);
+            const gptr_u16 sp = gslot + lead + (v << 2);
             const v4f_t m = {sp[0] < P ? 1.f : 0.f, sp[1] < P ? 1.f : 0.f, sp[2] < P ? 1.f : 0.f, sp[3] < P ? 1.f : 0.f};
             __builtin_nontemporal_store(m, (v4f_t*)(mrow + lead + (v << 2)));
         }
-        if (tid < G - tail0) mrow[tail0 + tid] = pat.slot[tail0 + tid] < P ? 1.f : 0.f;
+        if (tid < G - tail0) mrow[tail0 + tid] = gslot[tail0 + tid] < P ? 1.f : 0.f;
     }
 
     SlabArgs A;

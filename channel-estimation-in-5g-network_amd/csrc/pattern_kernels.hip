@@ -29,7 +29,10 @@
 
 namespace chest {
 
-constexpr int PB_THREADS = 256;
+#ifndef CHEST_PB_THREADS
+#define CHEST_PB_THREADS 256
+#endif
+constexpr int PB_THREADS = CHEST_PB_THREADS;      // >= 256 (the radix selection keeps its 256 bins on the first 256 threads)
 constexpr uint32_t TNONE = 0xFFFFu;
 constexpr int PB_MAX_ROWS = CHEST_MAX_SYMBOLS;
 
@@ -48,6 +51,7 @@ struct PatBuildArgs {
     int32_t* status;
 };
 
+struct alignas(16) TriRec { uint16_t h[6]; uint32_t claim; };
 __device__ __forceinline__ int px_of(uint32_t v) { return (int)(v >> 16); }
 __device__ __forceinline__ int py_of(uint32_t v) { return (int)(v & 0xFFFFu); }
 __device__ __forceinline__ int orient2(uint32_t a, uint32_t b, uint32_t c) {
@@ -95,7 +99,7 @@ __device__ __forceinline__ int2 block_exscan(int v, int* scr) {
 }
 
 size_t pattern_build_lds_bytes(int G, int Pcap) {
-    const size_t tri = (size_t)4 * Pcap + (size_t)2 * Pcap * (6 * 2 + 4 + 2);        // pts | tv, tn | claim | partner
+    const size_t tri = (size_t)4 * Pcap + 16 + (size_t)2 * Pcap * (sizeof(uint16_t) * 6 + 4 + 2);        // pts | triangle records | partner
     const size_t keys = (size_t)4 * G;
     return (tri > keys ? tri : keys) + (size_t)(PB_THREADS + 8 + 8 * (PB_MAX_ROWS + 2)) * sizeof(int) + 64;
 }
@@ -142,16 +146,15 @@ pattern_build_kernel(const PatBuildArgs A) {
     uint32_t* eown = (uint32_t*)(stack + PB_MAX_ROWS + 2);       //   owner of the edge (stack[i-1], stack[i]): tri << 2 | slot, or ~0u,
     int* eq = (int*)(eown + PB_MAX_ROWS + 2);                    //   strip of that edge if it is the bare chain edge of a strip without triangles,
     uint32_t* rung = (uint32_t*)(eq + PB_MAX_ROWS + 2);          //   and who owns such an edge after the left pass
-    unsigned char* big = (unsigned char*)(rung + PB_MAX_ROWS + 2);
-    big = (unsigned char*)(((uintptr_t)big + 15) & ~(uintptr_t)15);
-    uint32_t* keys = (uint32_t*)big;
-    uint32_t* pts = (uint32_t*)big;
-    uint16_t* tv0 = (uint16_t*)(pts + A.Pcap); uint16_t* tv1 = tv0 + NT; uint16_t* tv2 = tv1 + NT;
-    uint16_t* tn0 = tv2 + NT; uint16_t* tn1 = tn0 + NT; uint16_t* tn2 = tn1 + NT;
-    uint32_t* claim = (uint32_t*)(tn2 + NT);
-    uint16_t* partner = (uint16_t*)(claim + NT);
-    auto TV = [&](int c) -> uint16_t* { return c == 0 ? tv0 : (c == 1 ? tv1 : tv2); };
-    auto TN = [&](int c) -> uint16_t* { return c == 0 ? tn0 : (c == 1 ? tn1 : tn2); };
+    // (byte offsets from the LDS base, never pointer -> integer -> pointer: such a round trip loses the LDS address space and
+    // every access below becomes a FLAT instruction)
+    const unsigned off_big = ((unsigned)(PB_THREADS + 8 + 8 * (PB_MAX_ROWS + 2)) * 4u + 15u) & ~15u;
+    uint32_t* keys = (uint32_t*)(lds_raw + off_big);
+    uint32_t* pts = (uint32_t*)(lds_raw + off_big);
+    // one 16-B record per triangle: vertices h[0..3), neighbours across the edge opposite each vertex h[3..6), claim word
+    const unsigned off_tr = (off_big + 4u * (unsigned)A.Pcap + 15u) & ~15u;
+    TriRec* TR = (TriRec*)(lds_raw + off_tr);
+    uint16_t* partner = (uint16_t*)(lds_raw + off_tr + (unsigned)NT * (unsigned)sizeof(TriRec));
 
     // ================= 1. pilots =================================================================================
     const int per = (G + PB_THREADS - 1) / PB_THREADS;           // contiguous element block of this thread
@@ -176,14 +179,14 @@ pattern_build_kernel(const PatBuildArgs A) {
         uint32_t prefix = 0;
         int need = P;                                                         // rank of tau among the keys matching the prefix
         for (int shift = 24; shift >= 0; shift -= 8) {
-            scan[tid] = 0;                                                    // PB_THREADS == 256 bins
+            if (tid < 256) scan[tid] = 0;                                     // 256 bins
             __syncthreads();
             for (int g = g_lo; g < g_hi; ++g) {
                 const uint32_t kq = keys[g];
                 if (shift == 24 || (kq >> (shift + 8)) == prefix) atomicAdd(&scan[(kq >> shift) & 255u], 1);
             }
             __syncthreads();
-            const int h = scan[tid];
+            const int h = tid < 256 ? scan[tid] : 0;
             __syncthreads();
             const int2 ex = block_exscan(h, scan);                            // keys in lower bins
             if (ex.x < need && need <= ex.x + h) { cnt_s[0] = tid; cnt_s[4] = need - ex.x; }     // exactly one bin qualifies
@@ -285,9 +288,9 @@ pattern_build_kernel(const PatBuildArgs A) {
             const uint32_t kb = ((uint32_t)rb << 16) | nextcol;
             const int jb = count_less(pts + b0, nb, kb) - ((pts[b0] < kb) ? 1 : 0);
             const int k = i + jb, t = toff[q] + k, nq = na + nb - 2;
-            tv0[t] = (uint16_t)p; tv1[t] = (uint16_t)(b0 + jb); tv2[t] = (uint16_t)(p + 1);
-            tn0[t] = (uint16_t)(k + 1 < nq ? t + 1 : TNONE);     // rung after the step
-            tn2[t] = (uint16_t)(k > 0 ? t - 1 : TNONE);          // rung before the step
+            TR[t].h[0] = (uint16_t)p; TR[t].h[1] = (uint16_t)(b0 + jb); TR[t].h[2] = (uint16_t)(p + 1);
+            TR[t].h[3] = (uint16_t)(k + 1 < nq ? t + 1 : TNONE);     // rung after the step
+            TR[t].h[5] = (uint16_t)(k > 0 ? t - 1 : TNONE);          // rung before the step
             // across the row edge: the B-step of the strip above that advances over the same edge
             uint32_t up = TNONE;
             if (q > 0) {
@@ -296,7 +299,7 @@ pattern_build_kernel(const PatBuildArgs A) {
                 const int ia = count_leq(pts + u0, nu, ku) - ((pts[u0] <= ku) ? 1 : 0);     // A-steps before it (ties: upper row first)
                 up = (uint32_t)(toff[q - 1] + i + ia);
             }
-            tn1[t] = (uint16_t)up;
+            TR[t].h[4] = (uint16_t)up;
         }
         if (q > 0) {
             // B-step of strip q-1: triangle (b_j, b_{j+1}, a_i) with j = i here, i_A = #{i' >= 1 : colA[i'] <= col(b_{j+1})}
@@ -304,9 +307,9 @@ pattern_build_kernel(const PatBuildArgs A) {
             const uint32_t ku = ((uint32_t)ru << 16) | nextcol;
             const int ia = count_leq(pts + u0, nu, ku) - ((pts[u0] <= ku) ? 1 : 0);
             const int k = i + ia, t = toff[q - 1] + k, nq = nu + na - 2;
-            tv0[t] = (uint16_t)p; tv1[t] = (uint16_t)(p + 1); tv2[t] = (uint16_t)(u0 + ia);
-            tn0[t] = (uint16_t)(k + 1 < nq ? t + 1 : TNONE);     // rung after
-            tn1[t] = (uint16_t)(k > 0 ? t - 1 : TNONE);          // rung before
+            TR[t].h[0] = (uint16_t)p; TR[t].h[1] = (uint16_t)(p + 1); TR[t].h[2] = (uint16_t)(u0 + ia);
+            TR[t].h[3] = (uint16_t)(k + 1 < nq ? t + 1 : TNONE);     // rung after
+            TR[t].h[4] = (uint16_t)(k > 0 ? t - 1 : TNONE);          // rung before
             uint32_t dn = TNONE;
             if (q + 1 < m) {
                 const int rb = occ[q + 1], b0 = rowstart[rb], nb = rowstart[rb + 1] - b0;
@@ -314,7 +317,7 @@ pattern_build_kernel(const PatBuildArgs A) {
                 const int jb = count_less(pts + b0, nb, kb) - ((pts[b0] < kb) ? 1 : 0);
                 dn = (uint32_t)(toff[q] + i + jb);
             }
-            tn2[t] = (uint16_t)dn;
+            TR[t].h[5] = (uint16_t)dn;
         }
     }
     __syncthreads();
@@ -326,12 +329,12 @@ pattern_build_kernel(const PatBuildArgs A) {
         int nt = nstrip;
         auto link = [&](uint32_t own, int t, int c) {            // make `own` and slot c of triangle t neighbours
             if (own == 0xFFFFFFFFu) return;
-            TN(c)[t] = (uint16_t)(own >> 2);
-            TN((int)(own & 3u))[own >> 2] = (uint16_t)t;
+            TR[t].h[3 + (c)] = (uint16_t)(own >> 2);
+            TR[own >> 2].h[3 + ((int)(own & 3u))] = (uint16_t)t;
         };
         auto slot_of_edge = [&](int t, uint32_t x, uint32_t y) -> int {     // slot of t whose edge joins x and y
             for (int d = 0; d < 3; ++d) {
-                const uint32_t e0 = TV((d + 1) % 3)[t], e1 = TV((d + 2) % 3)[t];
+                const uint32_t e0 = TR[t].h[(d + 1) % 3], e1 = TR[t].h[(d + 2) % 3];
                 if ((e0 == x && e1 == y) || (e0 == y && e1 == x)) return d;
             }
             return 0;
@@ -360,8 +363,8 @@ pattern_build_kernel(const PatBuildArgs A) {
                     if (!(side == 0 ? o < 0 : o > 0)) break;
                     // counter-clockwise: (a, p, b) on the left chain, (a, b, p) on the right one
                     const int t = nt++;
-                    tv0[t] = (uint16_t)a; tv1[t] = (uint16_t)(side == 0 ? p : b); tv2[t] = (uint16_t)(side == 0 ? b : p);
-                    tn0[t] = tn1[t] = tn2[t] = (uint16_t)TNONE;
+                    TR[t].h[0] = (uint16_t)a; TR[t].h[1] = (uint16_t)(side == 0 ? p : b); TR[t].h[2] = (uint16_t)(side == 0 ? b : p);
+                    TR[t].h[3] = TR[t].h[4] = TR[t].h[5] = (uint16_t)TNONE;
                     const int s_ab = side == 0 ? 1 : 2;          // edge (a, b) is opposite p
                     const int s_bp = 0;                          // edge (b, p) is opposite a
                     const int s_ap = side == 0 ? 2 : 1;          // edge (a, p) is opposite b
@@ -392,7 +395,7 @@ pattern_build_kernel(const PatBuildArgs A) {
     // Every thread keeps the active set of its own triangles (t = tid + 256 i) as a register bit mask.
     constexpr uint32_t CLAIM_NONE = 0xFFFFFFFFu, CLAIM_DIRTY = 0xFFFFFFFEu;
     uint32_t active = 0;
-    for (int i = 0, t = tid; t < ntri; t += PB_THREADS, ++i) { claim[t] = CLAIM_DIRTY; partner[t] = (uint16_t)TNONE; active |= 1u << i; }
+    for (int i = 0, t = tid; t < ntri; t += PB_THREADS, ++i) { TR[t].claim = CLAIM_DIRTY; partner[t] = (uint16_t)TNONE; active |= 1u << i; }
     __syncthreads();
 #ifdef CHEST_STAMPS
     unsigned dbg_rounds = 0, dbg_cross = 0;
@@ -410,19 +413,19 @@ pattern_build_kernel(const PatBuildArgs A) {
         // phase 0: active triangles test their edges; an edge that fails the in-circle test claims both of its triangles
         for (uint32_t m = active; m != 0; m &= m - 1) {
             const int t = tid + PB_THREADS * (__ffs(m) - 1);
-            const uint32_t n[3] = {tn0[t], tn1[t], tn2[t]};
-            const uint32_t v[3] = {tv0[t], tv1[t], tv2[t]};
+            const uint32_t n[3] = {TR[t].h[3], TR[t].h[4], TR[t].h[5]};
+            const uint32_t v[3] = {TR[t].h[0], TR[t].h[1], TR[t].h[2]};
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
                 const uint32_t u = n[i];
-                if (u == TNONE || (u < (uint32_t)t && claim[u] != CLAIM_NONE)) continue;      // the other (active) side tests it
+                if (u == TNONE || (u < (uint32_t)t && TR[u].claim != CLAIM_NONE)) continue;      // the other (active) side tests it
                 const uint32_t b = v[(i + 1) % 3], c = v[(i + 2) % 3];
-                const uint32_t u0 = tv0[u], u1 = tv1[u], u2 = tv2[u];
+                const uint32_t u0 = TR[u].h[0], u1 = TR[u].h[1], u2 = TR[u].h[2];
                 const uint32_t d = (u0 != b && u0 != c) ? u0 : ((u1 != b && u1 != c) ? u1 : u2);
                 if (incircle(pts[v[i]], pts[b], pts[c], pts[d]) > 0) {
                     const uint32_t key = (uint32_t)t * 4u + (uint32_t)i;
-                    atomicMin(&claim[t], key);
-                    atomicMin(&claim[u], key);
+                    atomicMin(&TR[t].claim, key);
+                    atomicMin(&TR[u].claim, key);
                     cnt_s[3] = 1;
                 }
             }
@@ -434,22 +437,22 @@ pattern_build_kernel(const PatBuildArgs A) {
         // keep their OLD ids for now
         for (uint32_t m = active; m != 0; m &= m - 1) {
             const int t = tid + PB_THREADS * (__ffs(m) - 1);
-            const uint32_t key = claim[t];
+            const uint32_t key = TR[t].claim;
             if ((key >> 2) != (uint32_t)t) continue;             // the winning edge of t was tested from another triangle, or none
             const int i = (int)(key & 3u);
-            const uint32_t u = TN(i)[t];
-            if (claim[u] != key) continue;
-            const uint32_t a = TV(i)[t], b = TV((i + 1) % 3)[t], c = TV((i + 2) % 3)[t];
-            const uint32_t n_ab = TN((i + 2) % 3)[t], n_ca = TN((i + 1) % 3)[t];
-            const uint32_t u0 = tv0[u], u1 = tv1[u];
+            const uint32_t u = TR[t].h[3 + (i)];
+            if (TR[u].claim != key) continue;
+            const uint32_t a = TR[t].h[i], b = TR[t].h[(i + 1) % 3], c = TR[t].h[(i + 2) % 3];
+            const uint32_t n_ab = TR[t].h[3 + ((i + 2) % 3)], n_ca = TR[t].h[3 + ((i + 1) % 3)];
+            const uint32_t u0 = TR[u].h[0], u1 = TR[u].h[1];
             const int jd = (u0 != b && u0 != c) ? 0 : ((u1 != b && u1 != c) ? 1 : 2);
-            const uint32_t d = TV(jd)[u];
+            const uint32_t d = TR[u].h[jd];
             // u = (d, c, b) rotated so that u[jd] = d: the edge opposite c is (b, d), the edge opposite b is (d, c)
-            const uint32_t n_db = TN((jd + 1) % 3)[u], n_cd = TN((jd + 2) % 3)[u];
-            tv0[t] = (uint16_t)a; tv1[t] = (uint16_t)b; tv2[t] = (uint16_t)d;
-            tn0[t] = (uint16_t)n_db; tn1[t] = (uint16_t)u; tn2[t] = (uint16_t)n_ab;
-            tv0[u] = (uint16_t)a; tv1[u] = (uint16_t)d; tv2[u] = (uint16_t)c;
-            tn0[u] = (uint16_t)n_cd; tn1[u] = (uint16_t)n_ca; tn2[u] = (uint16_t)t;
+            const uint32_t n_db = TR[u].h[3 + ((jd + 1) % 3)], n_cd = TR[u].h[3 + ((jd + 2) % 3)];
+            TR[t].h[0] = (uint16_t)a; TR[t].h[1] = (uint16_t)b; TR[t].h[2] = (uint16_t)d;
+            TR[t].h[3] = (uint16_t)n_db; TR[t].h[4] = (uint16_t)u; TR[t].h[5] = (uint16_t)n_ab;
+            TR[u].h[0] = (uint16_t)a; TR[u].h[1] = (uint16_t)d; TR[u].h[2] = (uint16_t)c;
+            TR[u].h[3] = (uint16_t)n_cd; TR[u].h[4] = (uint16_t)n_ca; TR[u].h[5] = (uint16_t)t;
             partner[t] = (uint16_t)u; partner[u] = (uint16_t)t;
         }
         __syncthreads();
@@ -459,26 +462,26 @@ pattern_build_kernel(const PatBuildArgs A) {
         for (uint32_t m = active; m != 0; m &= m - 1) {
             const int t = tid + PB_THREADS * (__ffs(m) - 1);
             const uint32_t pT = partner[t];
-            if (pT == TNONE || (claim[t] >> 2) != (uint32_t)t) continue;
+            if (pT == TNONE || (TR[t].claim >> 2) != (uint32_t)t) continue;
 #pragma unroll
             for (int side = 0; side < 2; ++side) {
                 const int X = side == 0 ? t : (int)pT;
                 const uint32_t pX = side == 0 ? pT : (uint32_t)t;
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
-                    uint32_t Y = TN(k)[X];
+                    uint32_t Y = TR[X].h[3 + (k)];
                     if (Y == TNONE || Y == pX) continue;
-                    const uint32_t x = TV((k + 1) % 3)[X], y = TV((k + 2) % 3)[X];
+                    const uint32_t x = TR[X].h[(k + 1) % 3], y = TR[X].h[(k + 2) % 3];
                     const uint32_t pY = partner[Y];
                     if (pY != TNONE) {
-                        const uint32_t y0 = tv0[Y], y1 = tv1[Y], y2 = tv2[Y];
+                        const uint32_t y0 = TR[Y].h[0], y1 = TR[Y].h[1], y2 = TR[Y].h[2];
                         const bool has = (y0 == x || y1 == x || y2 == x) && (y0 == y || y1 == y || y2 == y);
                         if (!has) Y = pY;
-                        TN(k)[X] = (uint16_t)Y;
+                        TR[X].h[3 + (k)] = (uint16_t)Y;
                     } else {
-                        const uint32_t y0 = tv0[Y], y1 = tv1[Y];
+                        const uint32_t y0 = TR[Y].h[0], y1 = TR[Y].h[1];
                         const int k2 = (y0 != x && y0 != y) ? 0 : ((y1 != x && y1 != y) ? 1 : 2);
-                        TN(k2)[Y] = (uint16_t)X;
+                        TR[Y].h[3 + (k2)] = (uint16_t)X;
                     }
                 }
             }
@@ -488,10 +491,10 @@ pattern_build_kernel(const PatBuildArgs A) {
         // claimed triangles (flipped, or candidates that lost) are the next round's active set; marks that drew no claim clear
         active = 0;
         for (int i = 0, t = tid; t < ntri; t += PB_THREADS, ++i) {
-            const uint32_t c = claim[t];
+            const uint32_t c = TR[t].claim;
             if (c == CLAIM_NONE) continue;
             const bool act = c < CLAIM_DIRTY;
-            claim[t] = act ? CLAIM_DIRTY : CLAIM_NONE;
+            TR[t].claim = act ? CLAIM_DIRTY : CLAIM_NONE;
             partner[t] = (uint16_t)TNONE;
             if (act) active |= 1u << i;
         }
@@ -502,12 +505,12 @@ pattern_build_kernel(const PatBuildArgs A) {
     PSTAMP(5);                                                   // flips
     if (A.simp_out != nullptr) {
         int32_t* so = A.simp_out + (size_t)j * 2 * A.Pcap * 3;
-        for (int t = tid; t < ntri; t += PB_THREADS) { so[3 * t] = tv0[t]; so[3 * t + 1] = tv1[t]; so[3 * t + 2] = tv2[t]; }
+        for (int t = tid; t < ntri; t += PB_THREADS) { so[3 * t] = TR[t].h[0]; so[3 * t + 1] = TR[t].h[1]; so[3 * t + 2] = TR[t].h[2]; }
         if (A.nbr_out != nullptr) {
             int32_t* no = A.nbr_out + (size_t)j * 2 * A.Pcap * 3;
             for (int t = tid; t < ntri; t += PB_THREADS) {
-                no[3 * t] = tn0[t] == TNONE ? -1 : (int)tn0[t]; no[3 * t + 1] = tn1[t] == TNONE ? -1 : (int)tn1[t];
-                no[3 * t + 2] = tn2[t] == TNONE ? -1 : (int)tn2[t];
+                no[3 * t] = TR[t].h[3] == TNONE ? -1 : (int)TR[t].h[3]; no[3 * t + 1] = TR[t].h[4] == TNONE ? -1 : (int)TR[t].h[4];
+                no[3 * t + 2] = TR[t].h[5] == TNONE ? -1 : (int)TR[t].h[5];
             }
         }
         if (tid == 0 && A.nsimp_out) A.nsimp_out[j] = ntri;
@@ -527,7 +530,7 @@ pattern_build_kernel(const PatBuildArgs A) {
         uint32_t* __restrict__ v2t = (uint32_t*)partner;         // partner[] (2 * Pcap uint16) is free after the flips
         for (int i = tid; i < P; i += PB_THREADS) v2t[i] = 0xFFFFFFFFu;
         __syncthreads();
-        for (int t = tid; t < ntri; t += PB_THREADS) { atomicMin(&v2t[tv0[t]], (uint32_t)t); atomicMin(&v2t[tv1[t]], (uint32_t)t); atomicMin(&v2t[tv2[t]], (uint32_t)t); }
+        for (int t = tid; t < ntri; t += PB_THREADS) { atomicMin(&v2t[TR[t].h[0]], (uint32_t)t); atomicMin(&v2t[TR[t].h[1]], (uint32_t)t); atomicMin(&v2t[TR[t].h[2]], (uint32_t)t); }
         __syncthreads();
         auto near_tri = [&](int s_, int k_) -> int {
             const uint32_t q = ((uint32_t)s_ << 16) | (uint32_t)k_;
@@ -550,7 +553,7 @@ pattern_build_kernel(const PatBuildArgs A) {
         int since = 0;                                            // crossings since the last emitted element
         while (g < g_hi) {
             if (fresh) {
-                i0 = tv0[t]; i1 = tv1[t]; i2 = tv2[t];
+                i0 = TR[t].h[0]; i1 = TR[t].h[1]; i2 = TR[t].h[2];
                 const uint32_t a = pts[i0], b = pts[i1], c = pts[i2], q = ((uint32_t)s << 16) | (uint32_t)k;
                 o0 = orient2(b, c, q); o1 = orient2(c, a, q); o2 = orient2(a, b, q);
                 d0 = px_of(c) - px_of(b); d1 = px_of(a) - px_of(c); d2 = px_of(b) - px_of(a);   // d(orient(u, v, q)) / d(column of q) = v.x - u.x
@@ -558,9 +561,9 @@ pattern_build_kernel(const PatBuildArgs A) {
             }
             uint32_t nx = TNONE;
             bool cross = false;
-            if (o0 < 0) { nx = tn0[t]; cross = true; }
-            else if (o1 < 0) { nx = tn1[t]; cross = true; }
-            else if (o2 < 0) { nx = tn2[t]; cross = true; }
+            if (o0 < 0) { nx = TR[t].h[3]; cross = true; }
+            else if (o1 < 0) { nx = TR[t].h[4]; cross = true; }
+            else if (o2 < 0) { nx = TR[t].h[5]; cross = true; }
 #ifdef CHEST_STAMPS
             if (cross && nx != TNONE) ++dbg_cross;
 #endif
@@ -574,7 +577,7 @@ pattern_build_kernel(const PatBuildArgs A) {
                 // not reached on a Delaunay triangulation (the visibility walk is acyclic); exhaustive scan as a safety net
                 const uint32_t q = ((uint32_t)s << 16) | (uint32_t)k;
                 for (int u = 0; u < ntri; ++u) {
-                    const uint32_t j0 = tv0[u], j1 = tv1[u], j2 = tv2[u];
+                    const uint32_t j0 = TR[u].h[0], j1 = TR[u].h[1], j2 = TR[u].h[2];
                     const int p0 = orient2(pts[j1], pts[j2], q), p1 = orient2(pts[j2], pts[j0], q), p2 = orient2(pts[j0], pts[j1], q);
                     if ((p0 | p1 | p2) >= 0) {
                         const float den = (float)(p0 + p1 + p2);
