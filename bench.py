@@ -300,6 +300,9 @@ def run(args):
                 pils.append(np.sort(perm[: int(G * dens_list[di])]))
     else:
         npat = 1 if kind == "fullcov" else (F + group - 1) // group
+        # one pattern per frame: the pattern belongs to the frame (simulate_transmission draws it), so it is built inside
+        # the timed step from (seed, global frame index) unless --patterns-resident asks for the plans to be pre-built
+        per_step_patterns = device_patterns and group == 1 and kind == "frames" and not args.patterns_resident
         if device_patterns:
             slots = eng.build_patterns(0, np.full(npat, int(G * w["dens"]), np.int32), seed=2024, pattern_ids=np.arange(npat, dtype=np.uint64), method="linear")
             pils = [eng.get_pilots(int(slots[0]))] if kind == "fullcov" else [None] * npat
@@ -358,6 +361,7 @@ def run(args):
             slot_of_frame = np.asarray(slots, dtype=np.int32)[np.arange(F) // group]
             if args.with_metrics:
                 names.append("metrics")
+        npil_frames = np.full(F, int(G * w["dens"]), np.int32)
         descs = E.make_descs(w["ct"], w["fd"], w["snr"], slot_of_frame, n=F)
         d_first = torch.from_numpy(descs.view(np.uint8).copy()).to(eng.device)
 
@@ -393,6 +397,8 @@ def run(args):
             eng.run_frames(d_first, seed=seed, frame_offset=off, outputs=names, out=out, check=False)
             eng.mmse_full_apply_pilots(out["h_ls_pilots"], slots[0], W, out=out["H_mmse"], scratch=scr)
         else:
+            if per_step_patterns:
+                eng.build_patterns(0, npil_frames, seed=2024, pattern_ids=np.arange(off, off + F, dtype=np.uint64), method="linear")
             eng.run_frames(d_first, seed=seed, frame_offset=off, outputs=names, out=out, check=False)
 
     # est-MSE is evaluate_estimator's job, not part of the LS+MMSE step: one extra UNTIMED launch with the fused
@@ -511,6 +517,8 @@ def main():
     ap.add_argument("--pattern-group", type=int, default=PATTERN_GROUP,
                     help="frames sharing one pilot pattern + interpolation plan; 1 = a new random pattern per frame as the "
                          "reference draws them (plans built BEFORE the timed region)")
+    ap.add_argument("--patterns-resident", action="store_true",
+                    help="with --pattern-group 1 on a fixed-parameter workload: build the per-frame patterns once before the timed region")
     ap.add_argument("--patterns", default="device", choices=["device", "host"],
                     help="device: pilot patterns drawn, triangulated and planned on the GPU (default); host: legacy np.random "
                          "shuffle + Qhull on the host cores")

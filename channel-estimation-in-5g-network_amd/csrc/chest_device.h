@@ -93,6 +93,19 @@ __device__ __forceinline__ float2 pilot_divide(float2 y, float2 x) {
 // ordinals, and a "valid" flag.  'nearest' plans are (w0, w1) = (1, 0) with all three ordinals equal.
 struct PlanRec { float w0, w1; uint32_t i01, i2v; };
 
+// Pointers read out of the pattern table are generic to the compiler and would be dereferenced with FLAT instructions, which
+// count against the LDS / scalar-load counter as well (a wait for an LDS read then also waits for the outstanding prefetch from
+// HBM).  They always point to device memory: say so.
+#define CHEST_GLOBAL __attribute__((address_space(1)))
+typedef const CHEST_GLOBAL uint16_t* gptr_u16;
+typedef const CHEST_GLOBAL int32_t* gptr_i32;
+typedef uint32_t v4u_t __attribute__((ext_vector_type(4)));
+typedef const CHEST_GLOBAL v4u_t* gptr_plan;
+__device__ __forceinline__ PlanRec ld_plan(gptr_plan plan, int i) {     // one 16-B global load
+    const v4u_t v = plan[i];
+    return PlanRec{__uint_as_float(v.x), __uint_as_float(v.y), v.z, v.w};
+}
+
 __device__ __forceinline__ float2 interp(const PlanRec& p, const float2* __restrict__ hp, int stride, int r) {
     const float w2 = (p.i2v >> 16) ? (1.0f - p.w0 - p.w1) : 0.0f;
     const float2 a0 = hp[(p.i01 & 0xFFFFu) * stride + r], a1 = hp[(p.i01 >> 16) * stride + r],

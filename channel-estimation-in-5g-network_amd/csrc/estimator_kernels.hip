@@ -42,9 +42,9 @@ estimate_kernel(int S, int R, int T, int nsc, const PatternDev* __restrict__ pat
         for (int i = tid; i < P; i += nthr) { float2 h = hp[i]; hp[i] = make_float2(alpha * h.x, alpha * h.y); }
         __syncthreads();
     }
-    const PlanRec* __restrict__ plan = (const PlanRec*)pat.plan;
+    const gptr_plan plan = (gptr_plan)pat.plan;
     for (int g = tid; g < G; g += nthr) {
-        const float2 v = interp(plan[g], hp, 1, 0);
+        const float2 v = interp(ld_plan(plan, g), hp, 1, 0);
         const int s = g / nsc, k = g - s * nsc;
         H_est[frame_base + ((size_t)(s * R + r) * T + t) * nsc + k] = v;
     }

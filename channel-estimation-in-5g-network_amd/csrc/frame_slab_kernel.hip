@@ -21,14 +21,6 @@
 
 namespace chest {
 
-// Pointers read out of the pattern table are generic to the compiler and would be dereferenced with FLAT instructions, which
-// count against the LDS / scalar-load counter as well (a wait for an LDS read then also waits for the outstanding prefetch from
-// HBM).  They always point to device memory: say so.
-#define CHEST_GLOBAL __attribute__((address_space(1)))
-typedef const CHEST_GLOBAL uint16_t* gptr_u16;
-typedef const CHEST_GLOBAL int32_t* gptr_i32;
-typedef uint32_t v4u_t __attribute__((ext_vector_type(4)));
-typedef const CHEST_GLOBAL v4u_t* gptr_plan;
 typedef float v4f_t __attribute__((ext_vector_type(4)));
 typedef float v2f_t __attribute__((ext_vector_type(2)));
 
@@ -40,11 +32,6 @@ __device__ __forceinline__ void st16(float2* p, float4 v) {
 __device__ __forceinline__ void st8(float2* p, float2 a) {
     const v2f_t t = {a.x, a.y};
     __builtin_nontemporal_store(t, (v2f_t*)p);
-}
-
-__device__ __forceinline__ PlanRec ld_plan(gptr_plan plan, int i) {     // one 16-B global load
-    const v4u_t v = plan[i];
-    return PlanRec{__uint_as_float(v.x), __uint_as_float(v.y), v.z, v.w};
 }
 
 // Copy LDS segment l[0..n) to global g[0..n) (float2 elements; g and l wave-uniform with equal address mod 16).

@@ -178,10 +178,10 @@ interp_from_pilots_kernel(int S, int R, int T, int nsc, int Ppad, const PatternD
     const int r = tfold ? m % R : (m / T) % R, b = tfold ? m / R : m / (T * R);
     for (int i = threadIdx.x; i < P; i += blockDim.x) hp[i] = h[(size_t)m * Ppad + i];
     __syncthreads();
-    const PlanRec* __restrict__ plan = (const PlanRec*)pat.plan;
+    const gptr_plan plan = (gptr_plan)pat.plan;
     const size_t frame_base = (size_t)b * S * R * T * nsc;
     for (int g = threadIdx.x; g < G; g += blockDim.x) {
-        const float2 v = interp(plan[g], hp, 1, 0);
+        const float2 v = interp(ld_plan(plan, g), hp, 1, 0);
         const int s = g / nsc, k = g - s * nsc;
         for (int t = t0; t < t0 + nt; ++t) H_est[frame_base + ((size_t)(s * R + r) * T + t) * nsc + k] = v;
     }
@@ -202,12 +202,12 @@ interp_from_pilots_tfold_kernel(int S, int R, int T, int nsc, int Ppad, const Pa
     float2* row = hp + ((P + 1) & ~1);                              // [nsc]
     const int r = m % R, b = m / R;
     for (int i = tid; i < P; i += blockDim.x) hp[i] = h[(size_t)m * Ppad + i];
-    const PlanRec* __restrict__ plan = (const PlanRec*)pat.plan;
+    const gptr_plan plan = (gptr_plan)pat.plan;
     const int n = T * nsc;
     const float inv_nsc = 1.0f / (float)nsc;
     for (int s = 0; s < S; ++s) {
         __syncthreads();                                            // hp ready / previous symbol's row fully read
-        for (int k = tid; k < nsc; k += blockDim.x) row[k] = interp(plan[s * nsc + k], hp, 1, 0);
+        for (int k = tid; k < nsc; k += blockDim.x) row[k] = interp(ld_plan(plan, s * nsc + k), hp, 1, 0);
         __syncthreads();
         float2* __restrict__ g0 = H_est + ((size_t)(b * S + s) * R + r) * T * nsc;
         const int head = (int)(((uintptr_t)g0 & 127u) >> 3);
