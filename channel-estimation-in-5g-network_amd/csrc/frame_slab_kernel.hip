@@ -43,7 +43,17 @@ __device__ __forceinline__ void seg_store_edge(float2* __restrict__ g, const flo
     else if (e == -1) st8(g, l[0]);                           // odd head: element 0 sits alone in its 16-B slot
     else if (e >= 0 && e == n - 1) st8(g + e, l[e]);
 }
-__device__ __forceinline__ int seg_store(float2* __restrict__ g, const float2* __restrict__ l, int n, int q0, int qstep, int lane) {
+// The lane number is recomputed here (two instructions, opaque to the optimiser) instead of being passed in: under the
+// 96-register budget the compiler otherwise keeps it in SCRATCH across the compute stretch, and a scratch reload is a vector
+// memory operation whose s_waitcnt vmcnt(0) also waits for every store the wave still has in flight -- the store-out of one
+// segment would drain before the next one starts.
+__device__ __forceinline__ int lane_id_fresh() {
+    int l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    return l;
+}
+__device__ __forceinline__ int seg_store(float2* __restrict__ g, const float2* __restrict__ l, int n, int q0, int qstep) {
+    const int lane = lane_id_fresh();
     const int head = (int)(((uintptr_t)g & 127u) >> 3);
     const int nst = (head + n + 127) >> 7;
     const int off = 2 * lane - head;
@@ -346,9 +356,9 @@ __device__ __forceinline__ void slab_body(const SlabArgs& A) {
             STAMP_ADD(3);                                                        // W barrier A
             if (storer) {
                 int ph = wave;                                                   // rotate the stores of consecutive segments over the waves
-                if (rg == 0 && txb != nullptr) { const int n = seg_store(txb + e_tx, l_tx, ns * T * nsc, ph, nstw, lane); ph = (ph + nstw - n % nstw) % nstw; }
-                if (Hb != nullptr) { const int n = seg_store(Hb + e_h, l_h, ns * RG * T * nsc, ph, nstw, lane); ph = (ph + nstw - n % nstw) % nstw; }
-                if (rxb != nullptr) seg_store(rxb + e_rx, l_rx, ns * RG * nsc, ph, nstw, lane);
+                if (rg == 0 && txb != nullptr) { const int n = seg_store(txb + e_tx, l_tx, ns * T * nsc, ph, nstw); ph = (ph + nstw - n % nstw) % nstw; }
+                if (Hb != nullptr) { const int n = seg_store(Hb + e_h, l_h, ns * RG * T * nsc, ph, nstw); ph = (ph + nstw - n % nstw) % nstw; }
+                if (rxb != nullptr) seg_store(rxb + e_rx, l_rx, ns * RG * nsc, ph, nstw);
             }
             STAMP_ADD(4);                                                        // W store-out
         }
@@ -503,8 +513,8 @@ __device__ __forceinline__ void slab_body(const SlabArgs& A) {
             STAMP_ADD(10);                                                       // E barrier A
             if (storer) {
                 int ph = wave;
-                if (Lb != nullptr) { const int n = seg_store(Lb + e_h, l_l, ns * RG * T * nsc, ph, nstw, lane); ph = (ph + nstw - n % nstw) % nstw; }
-                if (Mb != nullptr) seg_store(Mb + e_h, l_m, ns * RG * T * nsc, ph, nstw, lane);
+                if (Lb != nullptr) { const int n = seg_store(Lb + e_h, l_l, ns * RG * T * nsc, ph, nstw); ph = (ph + nstw - n % nstw) % nstw; }
+                if (Mb != nullptr) seg_store(Mb + e_h, l_m, ns * RG * T * nsc, ph, nstw);
             }
             STAMP_ADD(11);                                                       // E store-out
         }

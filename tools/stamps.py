@@ -28,11 +28,16 @@ def main():
     eng.tune("frame_min_waves", int(sys.argv[2]) if len(sys.argv) > 2 else 0)
     G = geom.grid
     P = int(G * 0.1)
-    slots = []
-    for g in range((F + 1023) // 1024):
-        perm = np.arange(G); np.random.RandomState(2024 + g).shuffle(perm)
-        slots.append(eng.pattern_slot(np.sort(perm[:P]), "linear"))
-    descs = E.make_descs("EVA", 111.1, 10.0, np.asarray(slots, np.int32)[np.arange(F) // 1024], n=F)
+    per_frame = len(sys.argv) > 3 and sys.argv[3] == "pf"           # one device-built pattern (and plan) per frame
+    if per_frame:
+        sl = eng.build_patterns(0, np.full(F, P, np.int32), seed=2024, pattern_ids=np.arange(F, dtype=np.uint64), method="linear")
+        descs = E.make_descs("EVA", 111.1, 10.0, np.asarray(sl, np.int32), n=F)
+    else:
+        slots = []
+        for g in range((F + 1023) // 1024):
+            perm = np.arange(G); np.random.RandomState(2024 + g).shuffle(perm)
+            slots.append(eng.pattern_slot(np.sort(perm[:P]), "linear"))
+        descs = E.make_descs("EVA", 111.1, 10.0, np.asarray(slots, np.int32)[np.arange(F) // 1024], n=F)
     d_dev = torch.from_numpy(descs.view(np.uint8).copy()).to(eng.device)
     names = ["tx", "rx", "H", "H_ls", "H_mmse", "pilot_symbols", "pilot_mask"]
     out = eng.run_frames(d_dev, seed=1, outputs=names)
