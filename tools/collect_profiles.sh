@@ -10,6 +10,7 @@ cd $R
 if [ "$part" = bench ] || [ "$part" = all ]; then
   timeout -k 10 400 python bench.py > $O/bench_cfg2.json 2> $O/bench_cfg2.err
   timeout -k 10 300 python bench.py --pattern-group 1 --no-cpu-baseline > $O/bench_cfg2_pattern_per_frame.json 2>> $O/bench.err
+  timeout -k 10 300 python bench.py --pattern-group 1 --patterns-resident --no-cpu-baseline > $O/bench_cfg2_pattern_per_frame_resident.json 2>> $O/bench.err
   timeout -k 10 300 python bench.py --workload cfg1_siso_epa_ls --no-cpu-baseline > $O/bench_cfg1.json 2>> $O/bench.err
   timeout -k 10 300 python bench.py --workload cfg3_4x4_etu_mmse --no-cpu-baseline > $O/bench_cfg3.json 2>> $O/bench.err
   timeout -k 10 500 python bench.py --workload cfg4_dataset_mixed > $O/bench_cfg4.json 2>> $O/bench.err
@@ -38,5 +39,7 @@ if [ "$part" = tools ] || [ "$part" = all ]; then
   timeout -k 10 200 python tools/bench_patterns.py > $O/bench_patterns.txt 2>&1
   timeout -k 10 300 python tools/bench_prepare.py > $O/bench_prepare.txt 2>&1
   timeout -k 10 300 python tools/dropin_latency.py > $O/dropin_latency.txt 2>&1
+  timeout -k 10 300 python tools/bench_cubic.py > $O/bench_cubic.txt 2>&1
+  bash tools/pmc_sq.sh > $O/pmc_sq_frame_kernel.txt 2>&1
   echo tools done
 fi
