@@ -52,6 +52,16 @@ struct PatBuildArgs {
 };
 
 struct alignas(16) TriRec { uint16_t h[6]; uint32_t claim; };
+// a whole triangle record in one ds_read_b128 / ds_write_b128
+struct TriU { uint32_t v[3], n[3], claim; };
+__device__ __forceinline__ TriU ld_tri(const TriRec* TR, uint32_t t) {
+    const uint4 r = *(const uint4*)&TR[t];
+    return TriU{{r.x & 0xFFFFu, r.x >> 16, r.y & 0xFFFFu}, {r.y >> 16, r.z & 0xFFFFu, r.z >> 16}, r.w};
+}
+__device__ __forceinline__ void st_tri(TriRec* TR, uint32_t t, uint32_t v0, uint32_t v1, uint32_t v2, uint32_t n0, uint32_t n1, uint32_t n2,
+                                       uint32_t claim) {
+    *(uint4*)&TR[t] = make_uint4(v0 | (v1 << 16), v2 | (n0 << 16), n1 | (n2 << 16), claim);
+}
 __device__ __forceinline__ int px_of(uint32_t v) { return (int)(v >> 16); }
 __device__ __forceinline__ int py_of(uint32_t v) { return (int)(v & 0xFFFFu); }
 __device__ __forceinline__ int orient2(uint32_t a, uint32_t b, uint32_t c) {
@@ -410,23 +420,35 @@ pattern_build_kernel(const PatBuildArgs A) {
 #endif
         if (tid == 0) cnt_s[3] = 0;
         __syncthreads();
-        // phase 0: active triangles test their edges; an edge that fails the in-circle test claims both of its triangles
+        // phase 0: active triangles test their edges; an edge that fails the in-circle test claims both of its triangles.
+        // One 16-B read brings a triangle; the three neighbours and then the three opposite pilots are fetched together.
+        uint32_t prop = 0;                                       // my triangles that proposed a flip this round
         for (uint32_t m = active; m != 0; m &= m - 1) {
-            const int t = tid + PB_THREADS * (__ffs(m) - 1);
-            const uint32_t n[3] = {TR[t].h[3], TR[t].h[4], TR[t].h[5]};
-            const uint32_t v[3] = {TR[t].h[0], TR[t].h[1], TR[t].h[2]};
+            const int bit = __ffs(m) - 1;
+            const int t = tid + PB_THREADS * bit;
+            const TriU T0 = ld_tri(TR, (uint32_t)t);
+            const uint32_t pv[3] = {pts[T0.v[0]], pts[T0.v[1]], pts[T0.v[2]]};
+            TriU U[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) U[i] = ld_tri(TR, T0.n[i] == TNONE ? (uint32_t)t : T0.n[i]);
+            uint32_t pd[3];
+            bool need[3];
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
-                const uint32_t u = n[i];
-                if (u == TNONE || (u < (uint32_t)t && TR[u].claim != CLAIM_NONE)) continue;      // the other (active) side tests it
-                const uint32_t b = v[(i + 1) % 3], c = v[(i + 2) % 3];
-                const uint32_t u0 = TR[u].h[0], u1 = TR[u].h[1], u2 = TR[u].h[2];
-                const uint32_t d = (u0 != b && u0 != c) ? u0 : ((u1 != b && u1 != c) ? u1 : u2);
-                if (incircle(pts[v[i]], pts[b], pts[c], pts[d]) > 0) {
+                const uint32_t u = T0.n[i];
+                need[i] = !(u == TNONE || (u < (uint32_t)t && U[i].claim != CLAIM_NONE));       // else the other (active) side tests it
+                const uint32_t b = T0.v[(i + 1) % 3], c = T0.v[(i + 2) % 3];
+                const uint32_t d = (U[i].v[0] != b && U[i].v[0] != c) ? U[i].v[0] : ((U[i].v[1] != b && U[i].v[1] != c) ? U[i].v[1] : U[i].v[2]);
+                pd[i] = pts[need[i] ? d : T0.v[i]];
+            }
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                if (need[i] && incircle(pv[i], pv[(i + 1) % 3], pv[(i + 2) % 3], pd[i]) > 0) {
                     const uint32_t key = (uint32_t)t * 4u + (uint32_t)i;
                     atomicMin(&TR[t].claim, key);
-                    atomicMin(&TR[u].claim, key);
+                    atomicMin(&TR[T0.n[i]].claim, key);
                     cnt_s[3] = 1;
+                    prop |= 1u << bit;
                 }
             }
         }
@@ -434,54 +456,62 @@ pattern_build_kernel(const PatBuildArgs A) {
         DBG_PH(0);
         if (cnt_s[3] == 0) break;
         // phase 1: winners (an edge that holds the claim on both of its triangles) rewrite the two triangles; outer neighbours
-        // keep their OLD ids for now
-        for (uint32_t m = active; m != 0; m &= m - 1) {
-            const int t = tid + PB_THREADS * (__ffs(m) - 1);
-            const uint32_t key = TR[t].claim;
-            if ((key >> 2) != (uint32_t)t) continue;             // the winning edge of t was tested from another triangle, or none
+        // keep their OLD ids for now.  Only triangles that proposed can own a winning edge.
+        uint32_t won = 0;
+        for (uint32_t m = prop; m != 0; m &= m - 1) {
+            const int bit = __ffs(m) - 1;
+            const int t = tid + PB_THREADS * bit;
+            const TriU T0 = ld_tri(TR, (uint32_t)t);
+            const uint32_t key = T0.claim;
+            if ((key >> 2) != (uint32_t)t) continue;             // the winning edge of t was tested from another triangle
             const int i = (int)(key & 3u);
-            const uint32_t u = TR[t].h[3 + (i)];
-            if (TR[u].claim != key) continue;
-            const uint32_t a = TR[t].h[i], b = TR[t].h[(i + 1) % 3], c = TR[t].h[(i + 2) % 3];
-            const uint32_t n_ab = TR[t].h[3 + ((i + 2) % 3)], n_ca = TR[t].h[3 + ((i + 1) % 3)];
-            const uint32_t u0 = TR[u].h[0], u1 = TR[u].h[1];
-            const int jd = (u0 != b && u0 != c) ? 0 : ((u1 != b && u1 != c) ? 1 : 2);
-            const uint32_t d = TR[u].h[jd];
+            const uint32_t u = T0.n[i];
+            const TriU U0 = ld_tri(TR, u);
+            if (U0.claim != key) continue;
+            const uint32_t a = T0.v[i], b = T0.v[(i + 1) % 3], c = T0.v[(i + 2) % 3];
+            const uint32_t n_ab = T0.n[(i + 2) % 3], n_ca = T0.n[(i + 1) % 3];
+            const int jd = (U0.v[0] != b && U0.v[0] != c) ? 0 : ((U0.v[1] != b && U0.v[1] != c) ? 1 : 2);
+            const uint32_t d = U0.v[jd];
             // u = (d, c, b) rotated so that u[jd] = d: the edge opposite c is (b, d), the edge opposite b is (d, c)
-            const uint32_t n_db = TR[u].h[3 + ((jd + 1) % 3)], n_cd = TR[u].h[3 + ((jd + 2) % 3)];
-            TR[t].h[0] = (uint16_t)a; TR[t].h[1] = (uint16_t)b; TR[t].h[2] = (uint16_t)d;
-            TR[t].h[3] = (uint16_t)n_db; TR[t].h[4] = (uint16_t)u; TR[t].h[5] = (uint16_t)n_ab;
-            TR[u].h[0] = (uint16_t)a; TR[u].h[1] = (uint16_t)d; TR[u].h[2] = (uint16_t)c;
-            TR[u].h[3] = (uint16_t)n_cd; TR[u].h[4] = (uint16_t)n_ca; TR[u].h[5] = (uint16_t)t;
+            const uint32_t n_db = U0.n[(jd + 1) % 3], n_cd = U0.n[(jd + 2) % 3];
+            st_tri(TR, (uint32_t)t, a, b, d, n_db, u, n_ab, key);
+            st_tri(TR, u, a, d, c, n_cd, n_ca, (uint32_t)t, key);
             partner[t] = (uint16_t)u; partner[u] = (uint16_t)t;
+            won |= 1u << bit;
         }
         __syncthreads();
         DBG_PH(1);
         // phase 2: the owner of every flip resolves the outer neighbours of its two new triangles (the old neighbour, or its
         // partner if that one flipped too) and writes the back-pointer of neighbours that did not flip
-        for (uint32_t m = active; m != 0; m &= m - 1) {
+        for (uint32_t m = won; m != 0; m &= m - 1) {
             const int t = tid + PB_THREADS * (__ffs(m) - 1);
             const uint32_t pT = partner[t];
-            if (pT == TNONE || (TR[t].claim >> 2) != (uint32_t)t) continue;
 #pragma unroll
             for (int side = 0; side < 2; ++side) {
-                const int X = side == 0 ? t : (int)pT;
+                const uint32_t X = side == 0 ? (uint32_t)t : pT;
                 const uint32_t pX = side == 0 ? pT : (uint32_t)t;
+                const TriU TX = ld_tri(TR, X);
+                TriU TY[3];
+                uint32_t pY[3];
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
-                    uint32_t Y = TR[X].h[3 + (k)];
+                    const uint32_t Y = (TX.n[k] == TNONE || TX.n[k] == pX) ? X : TX.n[k];
+                    TY[k] = ld_tri(TR, Y);
+                    pY[k] = partner[Y];
+                }
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    uint32_t Y = TX.n[k];
                     if (Y == TNONE || Y == pX) continue;
-                    const uint32_t x = TR[X].h[(k + 1) % 3], y = TR[X].h[(k + 2) % 3];
-                    const uint32_t pY = partner[Y];
-                    if (pY != TNONE) {
-                        const uint32_t y0 = TR[Y].h[0], y1 = TR[Y].h[1], y2 = TR[Y].h[2];
+                    const uint32_t x = TX.v[(k + 1) % 3], y = TX.v[(k + 2) % 3];
+                    const uint32_t y0 = TY[k].v[0], y1 = TY[k].v[1], y2 = TY[k].v[2];
+                    if (pY[k] != TNONE) {
                         const bool has = (y0 == x || y1 == x || y2 == x) && (y0 == y || y1 == y || y2 == y);
-                        if (!has) Y = pY;
-                        TR[X].h[3 + (k)] = (uint16_t)Y;
+                        if (!has) Y = pY[k];
+                        TR[X].h[3 + k] = (uint16_t)Y;
                     } else {
-                        const uint32_t y0 = TR[Y].h[0], y1 = TR[Y].h[1];
                         const int k2 = (y0 != x && y0 != y) ? 0 : ((y1 != x && y1 != y) ? 1 : 2);
-                        TR[Y].h[3 + (k2)] = (uint16_t)X;
+                        TR[Y].h[3 + k2] = (uint16_t)X;
                     }
                 }
             }
