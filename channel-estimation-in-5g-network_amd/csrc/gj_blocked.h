@@ -27,6 +27,29 @@ __device__ __forceinline__ double gj_recip(double a) { return 1.0 / a; }
 __device__ __forceinline__ cdd gj_shfl(cdd v, int src) { return cdd{__shfl(v.x, src, 64), __shfl(v.y, src, 64)}; }
 __device__ __forceinline__ double gj_shfl(double v, int src) { return __shfl(v, src, 64); }
 
+// 16 x 16 result blocks on the float64 matrix pipe (v_mfma_f64_16x16x4_f64: A[row = lane & 15][k = lane >> 4], B[k = lane >> 4]
+// [col = lane & 15], result register j of a lane = element (row (lane >> 4) + 4 j, col lane & 15)).  The rate equals the
+// vector pipe's on gfx950; what it buys is one instruction and two LDS reads per 1 024 multiply-adds instead of sixteen and eight.
+typedef double v4d_t __attribute__((ext_vector_type(4)));
+template <class T> struct GjAcc;
+template <> struct GjAcc<double> {
+    v4d_t r;
+    __device__ __forceinline__ void zero() { r = v4d_t{0.0, 0.0, 0.0, 0.0}; }
+    __device__ __forceinline__ void mac(double a, double b) { r = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, r, 0, 0, 0); }
+    __device__ __forceinline__ double get(int j) const { return r[j]; }
+};
+template <> struct GjAcc<cdd> {
+    v4d_t r, i;
+    __device__ __forceinline__ void zero() { r = v4d_t{0.0, 0.0, 0.0, 0.0}; i = r; }
+    __device__ __forceinline__ void mac(cdd a, cdd b) {
+        r = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, b.x, r, 0, 0, 0);
+        r = __builtin_amdgcn_mfma_f64_16x16x4f64(-a.y, b.y, r, 0, 0, 0);
+        i = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, b.y, i, 0, 0, 0);
+        i = __builtin_amdgcn_mfma_f64_16x16x4f64(a.y, b.x, i, 0, 0, 0);
+    }
+    __device__ __forceinline__ cdd get(int j) const { return cdd{r[j], i[j]}; }
+};
+
 // A = R + s2 I is padded with an identity block to a multiple of GJB = 64 rows.  One step per 64-wide pivot block kb, two
 // launches per step (2 * ceil(P / 64) launches in all instead of the 2 P of an unblocked sweep):
 //   gjb_panel   every workgroup inverts the 64 x 64 pivot block D in LDS (64 pivots, no pivoting: the pivot blocks of a
@@ -66,7 +89,7 @@ __device__ __forceinline__ void tile_gemm_acc(const T* __restrict__ Xs, const T*
 
 template <class T>
 __device__ __forceinline__ void invert_pivot_block(T* __restrict__ D, T* __restrict__ Cs, int tid) {
-    // Cs: LDS scratch [64][16] for the saved sub-column panel
+    // Cs: LDS scratch [16][64] for the saved sub-column panel (transposed)
     for (int q = 0; q < GJB / 16; ++q) {
         const int o = 16 * q;
         if (tid < 64) {
@@ -94,46 +117,73 @@ __device__ __forceinline__ void invert_pivot_block(T* __restrict__ D, T* __restr
 #pragma unroll
             for (int m = 0; m < 4; ++m) D[(o + lr + 4 * m) * GJB + o + lc] = e[m];
         }
-        // save the old sub-column panel D[:, o..o+16) (rows outside the sub-block)
-        for (int x = tid; x < GJB * 16; x += 256) { const int i = x >> 4, c = x & 15; Cs[x] = D[i * GJB + o + c]; }
+        // save the old sub-column panel D[:, o..o+16), transposed (CsT[c][i]: consecutive rows on consecutive lanes of an A read)
+        for (int x = tid; x < GJB * 16; x += 256) { const int i = x & (GJB - 1), c = x >> 6; Cs[c * GJB + i] = D[i * GJB + o + c]; }
         __syncthreads();
-        // ---- sub-row panel: D[o.., j] = inv * D[o.., j] for the 48 columns j outside the sub-block -----------------
-        {
-            T acc[3];
-            const int r = tid >> 4, jj = tid & 15;                                   // row o + r, columns jj, jj + 16, jj + 32 of the 48
-            int col[3];
+        const int lane = tid & 63, wv = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
+        // ---- sub-row panel: D[o.., j] = inv * D[o.., j] for the three 16-column blocks outside the sub-block, one per wave
+        //      (16 x 16 x 16 products on the matrix pipe) ------------------------------------------------------------
+        const int cbk = wv < q ? wv : wv + 1;
+        GjAcc<T> pr;
+        pr.zero();
+        if (wv < 3) {
 #pragma unroll
-            for (int u = 0; u < 3; ++u) { const int j = jj + 16 * u; col[u] = j < o ? j : j + 16; acc[u] = T{}; }
-            for (int k = 0; k < 16; ++k) {
-                const T a = D[(o + r) * GJB + o + k];                                // inverse of the sub-block (written above)
-#pragma unroll
-                for (int u = 0; u < 3; ++u) gj_fma(acc[u], a, D[(o + k) * GJB + col[u]]);
+            for (int ks = 0; ks < 4; ++ks) {
+                const int k = 4 * ks + l4;
+                pr.mac(D[(o + l15) * GJB + o + k], D[(o + k) * GJB + 16 * cbk + l15]);
             }
-            __syncthreads();                                                         // all reads of the old sub-row panel done
+        }
+        __syncthreads();                                                             // all reads of the old sub-row panel done
+        if (wv < 3) {
 #pragma unroll
-            for (int u = 0; u < 3; ++u) D[(o + r) * GJB + col[u]] = acc[u];
+            for (int j = 0; j < 4; ++j) D[(o + l4 + 4 * j) * GJB + 16 * cbk + l15] = pr.get(j);
         }
         __syncthreads();
-        // ---- rest: D[i, j] -= C[i] R[j] (j outside), D[i, o..] = -C[i] inv, for the 48 rows i outside the sub-block -----
-        for (int x = tid; x < 48 * GJB; x += 256) {
-            const int ii = x / GJB, j = x % GJB;
-            const int i = ii < o ? ii : ii + 16;
-            const bool incol = j >= o && j < o + 16;
-            T acc{};
-            for (int k = 0; k < 16; ++k) gj_fma(acc, Cs[i * 16 + k], D[(o + k) * GJB + j]);   // j inside: the inverse; outside: the new sub-row panel
-            D[i * GJB + j] = incol ? gj_neg(acc) : gj_sub(D[i * GJB + j], acc);
+        // ---- rest: D[i, j] -= C[i] R[j] (j outside), D[i, o..] = -C[i] inv, for the three 16-row blocks outside the sub-block;
+        //      wave wv owns column block wv (rows o.. of D hold the inverse inside the sub-block and the new panel outside) ----
+#pragma unroll
+        for (int rbi = 0; rbi < 3; ++rbi) {
+            const int rbk = rbi < q ? rbi : rbi + 1;
+            GjAcc<T> acc;
+            acc.zero();
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int k = 4 * ks + l4;
+                acc.mac(Cs[k * GJB + 16 * rbk + l15], D[(o + k) * GJB + 16 * wv + l15]);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                T* d = D + (16 * rbk + l4 + 4 * j) * GJB + 16 * wv + l15;
+                *d = (wv == q) ? gj_neg(acc.get(j)) : gj_sub(*d, acc.get(j));
+            }
         }
         __syncthreads();
     }
 }
 
+// The first pivot block's inverse (one workgroup); every later one is produced by the update launch of the step before it.
 template <class T>
 __global__ void __launch_bounds__(256)
-gjb_panel_kernel(int Ppad, int kb, T* __restrict__ A, T* __restrict__ Dinv_g, T* __restrict__ Rp, T* __restrict__ Cp) {
+gjb_first_pivot_kernel(int Ppad, const T* __restrict__ A, T* __restrict__ Dinv_g) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    T* D = (T*)lds_raw;                            // [64][64] pivot block, inverted in place
+    T* D = (T*)lds_raw;
+    T* Cs = D + GJB * GJB;
+    const int tid = threadIdx.x;
+    for (int e = tid; e < GJB * GJB; e += 256) D[e] = A[(size_t)(e / GJB) * Ppad + e % GJB];
+    __syncthreads();
+    invert_pivot_block(D, Cs, tid);
+    for (int e = tid; e < GJB * GJB; e += 256) Dinv_g[e] = D[e];
+}
+
+// Step kb, first launch.  Column-tile workgroups w < nbk form the new pivot row panel Dinv * A[kb, w] (written to A and to Rp);
+// row-tile workgroups w >= nbk copy the old column panel A[i, kb] to Cp, so that the update reads neither while it is being
+// overwritten.  Dinv (the inverse of the pivot block) is already there: look-ahead of the previous update launch.
+template <class T>
+__global__ void __launch_bounds__(256)
+gjb_panel_kernel(int Ppad, int kb, T* __restrict__ A, const T* __restrict__ Dinv_g, T* __restrict__ Rp, T* __restrict__ Cp) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    T* D = (T*)lds_raw;                            // [64][64] inverse of the pivot block
     T* Ts = D + GJB * GJB;                         // [64][64] this workgroup's tile of the pivot row
-    T* Cs = Ts + GJB * GJB;                        // [64][16] scratch of the block inversion
     const int tid = threadIdx.x, nbk = Ppad / GJB, w = blockIdx.x;
     const size_t k0 = (size_t)kb * GJB;
     if (w >= nbk) {                                // row-tile job: save the old column panel A[i, kb]
@@ -144,15 +194,12 @@ gjb_panel_kernel(int Ppad, int kb, T* __restrict__ A, T* __restrict__ Dinv_g, T*
         }
         return;
     }
-    for (int e = tid; e < GJB * GJB; e += 256) D[e] = A[(k0 + e / GJB) * Ppad + k0 + e % GJB];
-    if (w != kb)
-        for (int e = tid; e < GJB * GJB; e += 256) Ts[e] = A[(k0 + e / GJB) * Ppad + (size_t)w * GJB + e % GJB];
-    __syncthreads();
-    invert_pivot_block(D, Cs, tid);
-    if (w == kb) {                                 // the inverse itself (the update kernel copies it into A[kb, kb])
-        for (int e = tid; e < GJB * GJB; e += 256) Dinv_g[e] = D[e];
-        return;
+    if (w == kb) return;                           // A[kb, kb] = Dinv is written by the update launch
+    for (int e = tid; e < GJB * GJB; e += 256) {
+        D[e] = Dinv_g[e];
+        Ts[e] = A[(k0 + e / GJB) * Ppad + (size_t)w * GJB + e % GJB];
     }
+    __syncthreads();
     // pivot row panel tile: Dinv * A[kb, w]
     const int ty = tid / 16, tx = tid % 16;
     T acc[4][4];
@@ -171,58 +218,111 @@ gjb_panel_kernel(int Ppad, int kb, T* __restrict__ A, T* __restrict__ Dinv_g, T*
         }
 }
 
+// Step kb, second launch: one workgroup per 64 x 64 tile (i, j), i != kb:  A[i, j] -= Cp_i Rp_j  (j != kb),
+// A[i, kb] = -Cp_i Dinv; tile (kb, kb) takes Dinv.  LOOK-AHEAD: the workgroup of tile (kb+1, kb+1) holds the next pivot block
+// in its registers after the update; it inverts it on the spot (LDS is free by then) and leaves the inverse in Dinv_next, so
+// that the 64-pivot sweep never sits on the critical path between two launches.
 template <class T>
 __global__ void __launch_bounds__(256)
-gjb_update_kernel(int Ppad, int kb, T* __restrict__ A, const T* __restrict__ Dinv_g, const T* __restrict__ Rp,
+gjb_update_kernel(int Ppad, int kb, T* __restrict__ A, const T* __restrict__ Dinv_g, T* __restrict__ Dinv_next, const T* __restrict__ Rp,
                   const T* __restrict__ Cp) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    T* Xs = (T*)lds_raw;                           // [64 rows][64 k]: Cp_i
-    T* Ys = Xs + GJB * GJB;                        // [64 k][64 cols]: Rp_j or Dinv
-    const int tid = threadIdx.x, ti = blockIdx.y, tj = blockIdx.x;
+    T* Xs = (T*)lds_raw;                           // one tile: the two operand halves; later the next pivot block
+    T* Ys = Xs + GJB * GJB;                        // [64][16] scratch of the look-ahead inversion
+    const int tid = threadIdx.x;
+    // the look-ahead tile (kb+1, kb+1) carries the longest job of the launch (update + 64-pivot sweep): it trades places with
+    // tile (0, 0) so that it is dispatched first
+    int ti = blockIdx.y, tj = blockIdx.x;
+    if (kb + 1 < (int)gridDim.x) {
+        if (ti == 0 && tj == 0) ti = tj = kb + 1;
+        else if (ti == kb + 1 && tj == kb + 1) ti = tj = 0;
+    }
     const size_t k0 = (size_t)kb * GJB;
     if (ti == kb) {
         if (tj == kb) for (int e = tid; e < GJB * GJB; e += 256) A[(k0 + e / GJB) * Ppad + k0 + e % GJB] = Dinv_g[e];
         return;                                    // the rest of the pivot row was written by the panel kernel
     }
     const bool colpanel = tj == kb;
-    for (int e = tid; e < GJB * GJB; e += 256) {
-        Xs[e] = Cp[(size_t)ti * GJB * GJB + e];
-        Ys[e] = colpanel ? Dinv_g[e] : Rp[(size_t)(e / GJB) * Ppad + (size_t)tj * GJB + e % GJB];
-    }
-    __syncthreads();
-    const int ty = tid / 16, tx = tid % 16;
-    T acc[4][4];
+    // wave w owns the 32 x 32 quadrant (w >> 1, w & 1) of the tile as 2 x 2 MFMA blocks
+    const int lane = tid & 63, wv = tid >> 6, wr = wv >> 1, wc = wv & 1, l15 = lane & 15, l4 = lane >> 4;
+    GjAcc<T> acc[2][2];
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
+    for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
-        for (int c = 0; c < 4; ++c) acc[r][c] = T{};
-    tile_gemm_acc(Xs, Ys, ty, tx, 0, GJB, acc);
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            T* dst = A + ((size_t)ti * GJB + 4 * ty + r) * Ppad + (size_t)tj * GJB + 4 * tx + c;
-            *dst = colpanel ? gj_neg(acc[r][c]) : gj_sub(*dst, acc[r][c]);
+        for (int cb = 0; cb < 2; ++cb) acc[rb][cb].zero();
+    // operands through LDS in two k-halves (X half [64][32 + 1 pad], Y half [32][64]): half the footprint, so that two
+    // workgroups share a CU and one's loads overlap the other's arithmetic; the pad keeps the 16 rows of an A read apart
+    constexpr int KH = GJB / 2, XP = KH + 1;
+    T* Xh = Xs;                                    // [64][XP]
+    T* Yh = Xs + GJB * XP;                         // [KH][64]
+    for (int half = 0; half < 2; ++half) {
+        if (half) __syncthreads();
+        for (int e = tid; e < GJB * KH; e += 256) {
+            const int r = e / KH, kk = e % KH;
+            Xh[r * XP + kk] = Cp[(size_t)ti * GJB * GJB + (size_t)r * GJB + half * KH + kk];
+            const int k = e / GJB, c = e % GJB;
+            Yh[e] = colpanel ? Dinv_g[(half * KH + k) * GJB + c] : Rp[(size_t)(half * KH + k) * Ppad + (size_t)tj * GJB + c];
         }
+        __syncthreads();
+#pragma unroll 2
+        for (int ks = 0; ks < KH / 4; ++ks) {
+            const int k = 4 * ks + l4;
+            T av[2], bv[2];
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb) av[rb] = Xh[(32 * wr + 16 * rb + l15) * XP + k];
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) bv[cb] = Yh[k * GJB + 32 * wc + 16 * cb + l15];
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                for (int cb = 0; cb < 2; ++cb) acc[rb][cb].mac(av[rb], bv[cb]);
+        }
+    }
+    const bool next_pivot = ti == kb + 1 && tj == kb + 1;          // workgroup-uniform
+    if (next_pivot) __syncthreads();                               // every thread is done reading the operand halves
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int row = 32 * wr + 16 * rb + l4 + 4 * j, col = 32 * wc + 16 * cb + l15;
+                T* dst = A + ((size_t)ti * GJB + row) * Ppad + (size_t)tj * GJB + col;
+                const T v = colpanel ? gj_neg(acc[rb][cb].get(j)) : gj_sub(*dst, acc[rb][cb].get(j));
+                *dst = v;
+                if (next_pivot) Xs[row * GJB + col] = v;
+            }
+    if (next_pivot) {
+        __syncthreads();
+        invert_pivot_block(Xs, Ys, tid);
+        for (int e = tid; e < GJB * GJB; e += 256) Dinv_next[e] = Xs[e];
+    }
 }
 
 
-// workspace elements (of T) behind the padded matrix A [Ppad][Ppad]: Rp [64][Ppad] | Cp [Ppad/64][64][64] | Dinv [64][64]
-inline size_t gj_aux_elems(int Ppad) { return (size_t)2 * GJB * Ppad + (size_t)GJB * GJB; }
+// workspace elements (of T) behind the padded matrix A [Ppad][Ppad]: Rp [64][Ppad] | Cp [Ppad/64][64][64] | Dinv x 2 [64][64]
+inline size_t gj_aux_elems(int Ppad) { return (size_t)2 * GJB * Ppad + (size_t)2 * GJB * GJB; }
 
-// In-place inverse of the padded matrix A [Ppad][Ppad] (Ppad a multiple of 64; pad with an identity block): 2 Ppad / 64 launches.
+// In-place inverse of the padded matrix A [Ppad][Ppad] (Ppad a multiple of 64; pad with an identity block): 2 Ppad / 64 + 1 launches.
 template <class T>
 int launch_gj_inverse(chest_ctx* ctx, hipStream_t st, int Ppad, T* A, T* aux, int lds_slot_panel, int lds_slot_update) {
     const int nbk = Ppad / GJB;
     T* Rp = aux;
     T* Cp = Rp + (size_t)GJB * Ppad;
-    T* Dinv = Cp + (size_t)GJB * Ppad;
-    CHEST_LDS_OPT_IN(ctx, lds_slot_panel, gjb_panel_kernel<T>, gjb_panel_lds<T>());
-    CHEST_LDS_OPT_IN(ctx, lds_slot_update, gjb_update_kernel<T>, 2 * gjb_tile_bytes<T>());
+    T* Dinv[2] = {Cp + (size_t)GJB * Ppad, Cp + (size_t)GJB * Ppad + (size_t)GJB * GJB};
+    CHEST_LDS_OPT_IN(ctx, lds_slot_panel, gjb_panel_kernel<T>, 2 * gjb_tile_bytes<T>());
+    const size_t lds_update = gjb_tile_bytes<T>() + (size_t)GJB * 16 * sizeof(T);          // 80 KiB (complex): two per CU
+    CHEST_LDS_OPT_IN(ctx, lds_slot_update, gjb_update_kernel<T>, lds_update);
+    // the first-pivot kernel shares the panel kernel's LDS slot bookkeeping (same size class)
+    if (hipFuncSetAttribute((const void*)gjb_first_pivot_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gjb_panel_lds<T>()) != hipSuccess) {
+        set_error("hipFuncSetAttribute(gjb_first_pivot_kernel) failed");
+        return CHEST_EHIP;
+    }
+    hipLaunchKernelGGL(gjb_first_pivot_kernel<T>, dim3(1), dim3(256), gjb_panel_lds<T>(), st, Ppad, (const T*)A, Dinv[0]);
     for (int kb = 0; kb < nbk; ++kb) {
-        hipLaunchKernelGGL(gjb_panel_kernel<T>, dim3((unsigned)(2 * nbk)), dim3(256), gjb_panel_lds<T>(), st, Ppad, kb, A, Dinv, Rp, Cp);
-        hipLaunchKernelGGL(gjb_update_kernel<T>, dim3((unsigned)nbk, (unsigned)nbk), dim3(256), 2 * gjb_tile_bytes<T>(), st, Ppad, kb, A,
-                           (const T*)Dinv, (const T*)Rp, (const T*)Cp);
+        hipLaunchKernelGGL(gjb_panel_kernel<T>, dim3((unsigned)(2 * nbk)), dim3(256), 2 * gjb_tile_bytes<T>(), st, Ppad, kb, A, (const T*)Dinv[kb & 1], Rp, Cp);
+        hipLaunchKernelGGL(gjb_update_kernel<T>, dim3((unsigned)nbk, (unsigned)nbk), dim3(256), lds_update, st, Ppad, kb, A,
+                           (const T*)Dinv[kb & 1], Dinv[(kb + 1) & 1], (const T*)Rp, (const T*)Cp);
     }
     return CHEST_OK;
 }

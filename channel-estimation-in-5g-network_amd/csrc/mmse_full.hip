@@ -354,7 +354,7 @@ int64_t chest_mmse_full_workspace_bytes(int32_t P) {
     if (P <= 0) return 0;
     const int64_t Ppad = ((int64_t)P + GJB - 1) / GJB * GJB;
     // A [Ppad][Ppad] | Rp [64][Ppad] | Cp [Ppad / 64][64][64] | Dinv [64][64], complex float64
-    return (int64_t)sizeof(double) * 2 * (Ppad * Ppad + 2 * GJB * Ppad + GJB * GJB);
+    return (int64_t)sizeof(double) * 2 * (Ppad * Ppad + (int64_t)gj_aux_elems((int)Ppad));
 }
 
 int chest_mmse_full_prepare(chest_ctx* ctx, void* stream, int32_t P, const double* cov, float snr_db, float* W,

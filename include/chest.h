@@ -286,8 +286,9 @@ int chest_qam_demodulate(chest_ctx* ctx, void* stream, int32_t M, int64_t num_sy
 int chest_bit_errors(chest_ctx* ctx, void* stream, int64_t n, const uint8_t* a, const uint8_t* b, uint64_t* count);
 
 /* Full-covariance MMSE (MMSEEstimator(channel_covariance=R, estimate_statistics=False), :181-190).
- * prepare: W = R (R + sigma^2 I)^-1 = I - sigma^2 (R + sigma^2 I)^-1 in float64 on the device (in-place Gauss-Jordan
- *          inversion of the Hermitian positive definite R + sigma^2 I, no pivoting), stored as c64
+ * prepare: W = R (R + sigma^2 I)^-1 = I - sigma^2 (R + sigma^2 I)^-1 in float64 on the device (blocked in-place
+ *          Gauss-Jordan inversion of the Hermitian positive definite R + sigma^2 I on the f64 matrix pipe, 64-wide
+ *          pivot blocks, no pivoting), stored as c64
  *          W [P][P]; cov is DEVICE complex128 [P][P] (interleaved doubles).
  * apply  : h_mmse = W h_ls for B*R*T right-hand sides on the f32 MFMA pipe, then interpolation with
  *          the slot's plan -> H_est [B][S][R][T][nsc]. */

@@ -17,10 +17,12 @@ for P in (838, 419):
     t0 = time.perf_counter(); simp, nbr = IP.delaunay_with_neighbors(ps, pk); t_q = time.perf_counter() - t0
     slot = eng.pattern_slot(idx, "linear", plan=simp)
     A = eng.cubic_operator_from_triangulation(slot, simp, nbr)
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    for _ in range(5):
+    ts = []
+    for _ in range(7):                      # each build timed on its own; the median ignores host hiccups after Qhull
+        torch.cuda.synchronize(); t0 = time.perf_counter()
         A = eng.cubic_operator_from_triangulation(slot, simp, nbr)
-    torch.cuda.synchronize(); t_d = (time.perf_counter() - t0) / 5
+        torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
+    t_d = float(np.median(ts))
     t0 = time.perf_counter(); ref = IP.cubic_operator(ps, pk, S, nsc); t_h = time.perf_counter() - t0
     err = float(np.max(np.abs(A.cpu().numpy() - ref)))
     B = 1024
