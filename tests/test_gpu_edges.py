@@ -219,6 +219,20 @@ def test_full_covariance_mmse_at_baseline_sizes(N, cp, U, T, R, B):
                 assert relerr(got[b, :, r, t, :], want) < TOL
 
 
+@pytest.mark.parametrize("P", [3, 63, 64, 65, 130, 200])
+def test_full_covariance_prepare_at_block_boundaries(P):
+    """Blocked Gauss-Jordan with 64-wide pivot blocks: fewer pilots than one block, exactly one, one more (identity padding),
+    and a few blocks (look-ahead inversion of the next pivot block) -- W against float64 NumPy."""
+    eng = E.get_engine(E.Geometry(useful_subcarriers=300), 0)
+    rs = np.random.RandomState(P)
+    Xr = rs.randn(P, 2 * P) + 1j * rs.randn(P, 2 * P)
+    cov = Xr @ Xr.conj().T / (2 * P)                           # Hermitian positive definite
+    for snr in (0.0, 20.0):
+        W = eng.mmse_full_prepare(cov, snr).cpu().numpy()
+        Wref = cov @ np.linalg.inv(cov + 10 ** (-snr / 10) * np.eye(P))
+        assert relerr(W, Wref) < 1e-6
+
+
 def test_place_outputs_returns_usable_buffers():
     """Engine.place_outputs only chooses WHERE the output tensors live: the buffers it returns have the documented shapes
     and a run into them equals a run into fresh allocations bit for bit."""
