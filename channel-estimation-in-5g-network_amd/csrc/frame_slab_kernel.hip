@@ -200,11 +200,17 @@ __device__ __forceinline__ void slab_body(const SlabArgs& A) {
     STAMP(st_a);
 
     // ---- phase W: per unit (symbols, rx group) assemble tx / H / rx rows in the slab, then stream them out -----------
-    uint32_t sln[SSN][2];                                                        // slot entries, one unit ahead
+    // Slot entries (which resource elements are pilots, and their ordinals).  Injected draws need them at the top of a unit,
+    // so that path fetches them one unit ahead; the device-RNG path needs them only when the unit's rows go into the slab:
+    // it issues the loads at the top of the unit and lets the synthesis cover them.  (A value prefetched across the store-out
+    // is consumed behind an s_waitcnt vmcnt(0) that also waits for every store of that store-out.)
+    uint32_t sln[SSN][2];
+    if constexpr (INJ) {
 #pragma unroll
-    for (int ss = 0; ss < SSN; ++ss) {
-        const int sy = ss < S ? ss : S - 1;
-        sln[ss][0] = slots[sy * nsc + kc0]; sln[ss][1] = slots[sy * nsc + kc1];
+        for (int ss = 0; ss < SSN; ++ss) {
+            const int sy = ss < S ? ss : S - 1;
+            sln[ss][0] = slots[sy * nsc + kc0]; sln[ss][1] = slots[sy * nsc + kc1];
+        }
     }
     for (int sb = 0; sb < S; sb += SSN) {
         const int ns = SSN == 1 ? 1 : min(SSN, S - sb);                          // symbols of this unit (ragged last unit)
@@ -213,9 +219,14 @@ __device__ __forceinline__ void slab_body(const SlabArgs& A) {
         bool pp[SSN][2];
 #pragma unroll
         for (int ss = 0; ss < SSN; ++ss) {
-            sc[ss][0] = sln[ss][0]; sc[ss][1] = sln[ss][1];
-            const int sn = sb + SSN + ss;
-            if (sn < S) { sln[ss][0] = slots[sn * nsc + kc0]; sln[ss][1] = slots[sn * nsc + kc1]; }
+            if constexpr (INJ) {
+                sc[ss][0] = sln[ss][0]; sc[ss][1] = sln[ss][1];
+                const int sn = sb + SSN + ss;
+                if (sn < S) { sln[ss][0] = slots[sn * nsc + kc0]; sln[ss][1] = slots[sn * nsc + kc1]; }
+            } else {
+                const int sy = sb + ss < S ? sb + ss : S - 1;
+                sc[ss][0] = slots[sy * nsc + kc0]; sc[ss][1] = slots[sy * nsc + kc1];
+            }
             float u0, u1;
             if (usym != nullptr) {
                 u0 = usym[sc[ss][0]]; u1 = usym[sc[ss][1]];
@@ -428,6 +439,19 @@ __device__ __forceinline__ void slab_body(const SlabArgs& A) {
         cn[ss][0] = ld_plan(plan, sy * nsc + kc0); cn[ss][1] = ld_plan(plan, sy * nsc + kc1);
     }
     first_unit = true;
+    // STAGED: a unit's estimates are gathered into registers one unit AHEAD, between the "slab complete" barrier of the unit
+    // before and that unit's store-out -- the plan records they need were requested a barrier pair earlier and no store sits
+    // between request and use (a value fetched across a store-out is consumed behind an s_waitcnt vmcnt(0) that drains the
+    // wave's stores).
+    constexpr int EVR = STAGED ? RGT : 1;
+    float2 ev[SSN][EVR][2];
+    auto gather = [&](const PlanRec (&c)[SSN][2], int r0, float2 (&e)[SSN][EVR][2]) {
+#pragma unroll
+        for (int ss = 0; ss < SSN; ++ss)
+#pragma unroll
+            for (int rr = 0; rr < EVR; ++rr) { e[ss][rr][0] = interp(c[ss][0], hp, R, r0 + rr); e[ss][rr][1] = interp(c[ss][1], hp, R, r0 + rr); }
+    };
+    if constexpr (STAGED) gather(cn, 0, ev);
     STAMP_ADD(6);                                                                // pilot outputs + alpha
     for (int sb = 0; sb < S; sb += SSN) {
         const int ns = SSN == 1 ? 1 : min(SSN, S - sb);
@@ -443,14 +467,7 @@ __device__ __forceinline__ void slab_body(const SlabArgs& A) {
             const unsigned e_h = (unsigned)((sb * R + r0) * T) * (unsigned)nsc;
             float2* __restrict__ l_l = slab + seg_l + ((par_h + e_h) & 1);
             float2* __restrict__ l_m = slab + seg_m + ((par_h + e_h) & 1);
-            // the unit's estimates first (registers; reads hp only), then the slab hand-over
-            float2 ev[SSN][STAGED ? RGT : 1][2];
-            if constexpr (STAGED) {
-#pragma unroll
-                for (int ss = 0; ss < SSN; ++ss)
-#pragma unroll
-                    for (int rr = 0; rr < RGT; ++rr) { ev[ss][rr][0] = interp(cc[ss][0], hp, R, r0 + rr); ev[ss][rr][1] = interp(cc[ss][1], hp, R, r0 + rr); }
-            }
+            const bool more = rg + 1 < ngroups || sb + SSN < S;                  // another unit follows (uniform)
             if (want_metrics) {
                 // sum_t |H_t - v|^2 = sum_t |H_t - Hbar|^2 + T |Hbar - v|^2 ; the first term is
                 // estimate-independent and comes analytically from K1 (ST_SUM_VAR).
@@ -484,8 +501,11 @@ __device__ __forceinline__ void slab_body(const SlabArgs& A) {
                     }
                 }
             }
-            if (Lb == nullptr && Mb == nullptr) continue;                        // metrics only: nothing to stream (uniform)
-            STAMP_ADD(7);                                                        // E compute (plan gather)
+            if (Lb == nullptr && Mb == nullptr) {                                // metrics only: nothing to stream (uniform)
+                if constexpr (STAGED) { if (more) { if (rg + 1 < ngroups) gather(cc, r0 + RG, ev); else gather(cn, 0, ev); } }
+                continue;
+            }
+            STAMP_ADD(7);                                                        // E compute (metrics)
             if (!first_unit) __syncthreads();
             first_unit = false;
             STAMP_ADD(8);                                                        // E barrier B
@@ -511,6 +531,9 @@ __device__ __forceinline__ void slab_body(const SlabArgs& A) {
             STAMP_ADD(9);                                                        // E slab writes
             __syncthreads();
             STAMP_ADD(10);                                                       // E barrier A
+            if constexpr (STAGED) {                                              // the next unit's estimates, ahead of this unit's stores
+                if (more) { if (rg + 1 < ngroups) gather(cc, r0 + RG, ev); else gather(cn, 0, ev); }
+            }
             if (storer) {
                 int ph = wave;
                 if (Lb != nullptr) { const int n = seg_store(Lb + e_h, l_l, ns * RG * T * nsc, ph, nstw); ph = (ph + nstw - n % nstw) % nstw; }
