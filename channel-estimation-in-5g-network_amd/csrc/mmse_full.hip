@@ -353,7 +353,7 @@ extern "C" {
 int64_t chest_mmse_full_workspace_bytes(int32_t P) {
     if (P <= 0) return 0;
     const int64_t Ppad = ((int64_t)P + GJB - 1) / GJB * GJB;
-    // A [Ppad][Ppad] | Rp [64][Ppad] | Cp [Ppad / 64][64][64] | Dinv [64][64], complex float64
+    // A [Ppad][Ppad] | Rp [64][Ppad] | Cp [Ppad / 64][64][64] | Dinv x 2 [64][64] (current + look-ahead), complex float64
     return (int64_t)sizeof(double) * 2 * (Ppad * Ppad + (int64_t)gj_aux_elems((int)Ppad));
 }
 

@@ -30,7 +30,7 @@ def test_version_and_error_channel_work_without_gpu():
     L = N.lib()
     assert L.chest_abi_version() == N.ABI_VERSION
     assert L.chest_frames_workspace_bytes(None, 10) == 0
-    assert L.chest_mmse_full_workspace_bytes(100) == 16 * (128 * 128 + 2 * 64 * 128 + 64 * 64)      # padded to the 64-wide pivot blocks
+    assert L.chest_mmse_full_workspace_bytes(100) == 16 * (128 * 128 + 2 * 64 * 128 + 2 * 64 * 64)  # padded to the 64-wide pivot blocks; two pivot-inverse buffers (look-ahead)
     h = ctypes.c_void_p()
     bad = N.Config(1000, 72, 14, 600, 15000.0, 2, 2, 0)          # S*nsc fine, but U > fft is rejected before any HIP call
     bad.useful_subcarriers = 5000
