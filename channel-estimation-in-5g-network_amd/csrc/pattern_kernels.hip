@@ -34,6 +34,8 @@ namespace chest {
 #endif
 constexpr int PB_THREADS = CHEST_PB_THREADS;      // >= 256 (the radix selection keeps its 256 bins on the first 256 threads)
 constexpr uint32_t TNONE = 0xFFFFu;
+constexpr int SEL_SHIFT = 20, SEL_BINS = 1 << (32 - SEL_SHIFT);      // pilot selection: histogram over the keys' top 12 bits
+constexpr int SEL_LIST = 256;                                        // capacity of the threshold bin's element list (mean G / 4096 <= 16)
 constexpr int PB_MAX_ROWS = CHEST_MAX_SYMBOLS;
 
 struct PatBuildArgs {
@@ -62,6 +64,10 @@ __device__ __forceinline__ void st_tri(TriRec* TR, uint32_t t, uint32_t v0, uint
                                        uint32_t claim) {
     *(uint4*)&TR[t] = make_uint4(v0 | (v1 << 16), v2 | (n0 << 16), n1 | (n2 << 16), claim);
 }
+// x[i mod 3] for i in 0 .. 4 without a run-time subscript
+__device__ __forceinline__ uint32_t sel3(const uint32_t (&x)[3], int i) {
+    return (i == 0 || i == 3) ? x[0] : ((i == 1 || i == 4) ? x[1] : x[2]);
+}
 __device__ __forceinline__ int px_of(uint32_t v) { return (int)(v >> 16); }
 __device__ __forceinline__ int py_of(uint32_t v) { return (int)(v & 0xFFFFu); }
 __device__ __forceinline__ int orient2(uint32_t a, uint32_t b, uint32_t c) {
@@ -89,6 +95,18 @@ __device__ __forceinline__ int count_leq(const uint32_t* a, int n, uint32_t key)
     return lo;
 }
 
+// number of j in [0, n - 1) with col(a[j]) + col(a[j + 1]) < key / <= key (a: one row's pilots, ascending columns)
+__device__ __forceinline__ int count_pairsum_less(const uint32_t* a, int n, int key) {
+    int lo = 0, hi = n - 1;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (py_of(a[mid]) + py_of(a[mid + 1]) < key) lo = mid + 1; else hi = mid; }
+    return lo;
+}
+__device__ __forceinline__ int count_pairsum_leq(const uint32_t* a, int n, int key) {
+    int lo = 0, hi = n - 1;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (py_of(a[mid]) + py_of(a[mid + 1]) <= key) lo = mid + 1; else hi = mid; }
+    return lo;
+}
+
 // exclusive scan of one value per thread over the workgroup (wave shuffles + one LDS hop); `scr` >= 8 ints of LDS;
 // returns (exclusive prefix, total)
 __device__ __forceinline__ int2 block_exscan(int v, int* scr) {
@@ -108,9 +126,58 @@ __device__ __forceinline__ int2 block_exscan(int v, int* scr) {
     return make_int2(base + incl - v, tot);
 }
 
+
+// position of the j-th (0-based) set bit of b (j < popcount(b)); b is wave-uniform, j per lane: vector ALU only
+__device__ __forceinline__ int nth_set_bit(uint64_t b, int j) {
+    int pos = 0;
+    uint32_t w = (uint32_t)b;
+    int c = __popc(w);
+    if (j >= c) { j -= c; pos = 32; w = (uint32_t)(b >> 32); }
+    c = __popc(w & 0xFFFFu); if (j >= c) { j -= c; pos += 16; w >>= 16; }
+    c = __popc(w & 0xFFu);   if (j >= c) { j -= c; pos += 8;  w >>= 8; }
+    c = __popc(w & 0xFu);    if (j >= c) { j -= c; pos += 4;  w >>= 4; }
+    c = __popc(w & 0x3u);    if (j >= c) { j -= c; pos += 2;  w >>= 2; }
+    if (j >= (int)(w & 1u)) pos += 1;
+    return pos;
+}
+
+// Work items are bits of per-lane masks (item = (owner lane, bit)).  The masks of a wave are uneven -- in a flip round the
+// busiest lane holds two to three times the average -- and a loop over the lane's own bits runs as long as the busiest lane,
+// each pass a chain of dependent LDS reads.  Here level p of the masks (the p-th item of every lane that has one; a ballot)
+// is packed together with the following levels while they fit into the 64 lanes of one pass: lane l of a pass takes the
+// (l - offset)-th lane of its level's ballot (vector ALU on the uniform ballot word) and reads that lane's mask with one
+// ds_bpermute.  fn(owner_lane, bit) runs on about ceil(items / 64) passes instead of max-items-per-lane passes.  All control
+// flow here is wave-uniform; no barrier or cross-lane operation may occur inside fn.
+template <class F>
+__device__ __forceinline__ void wave_balanced(uint32_t mask, int lane, F&& fn) {
+    const int cnt = __popc(mask);
+    if (__ballot(cnt > 1) == 0) {                               // nothing to balance (most rounds after the first few)
+        if (mask != 0) fn(lane, __ffs(mask) - 1);
+        return;
+    }
+    int p = 0;
+    uint64_t Bp = __ballot(cnt > 0);
+    while (Bp != 0) {
+        int filled = 0, owner = -1, level = 0;
+        do {
+            const int np = __popcll(Bp);
+            if (filled + np > 64) break;                        // (the first level of a pass always fits)
+            const int j = lane - filled;
+            if (j >= 0 && j < np) { owner = nth_set_bit(Bp, j); level = p; }
+            filled += np;
+            ++p;
+            Bp = __ballot(cnt > p);
+        } while (Bp != 0);
+        uint32_t m = __shfl(mask, owner < 0 ? lane : owner, 64);
+        for (int q = 0; q < level; ++q) m &= m - 1;
+        if (owner >= 0) fn(owner, __ffs(m) - 1);
+    }
+}
+
 size_t pattern_build_lds_bytes(int G, int Pcap) {
     const size_t tri = (size_t)4 * Pcap + 16 + (size_t)2 * Pcap * (sizeof(uint16_t) * 6 + 4 + 2);        // pts | triangle records | partner
-    const size_t keys = (size_t)4 * G;
+    const size_t keys = (size_t)4 * (SEL_BINS + 2 * SEL_LIST);                                        // selection: histogram + threshold-bin list
+    (void)G;
     return (tri > keys ? tri : keys) + (size_t)(PB_THREADS + 8 + 8 * (PB_MAX_ROWS + 2)) * sizeof(int) + 64;
 }
 
@@ -158,8 +225,11 @@ pattern_build_kernel(const PatBuildArgs A) {
     uint32_t* rung = (uint32_t*)(eq + PB_MAX_ROWS + 2);          //   and who owns such an edge after the left pass
     // (byte offsets from the LDS base, never pointer -> integer -> pointer: such a round trip loses the LDS address space and
     // every access below becomes a FLAT instruction)
+    // flip rounds (selection scan and row tables are dead by then): per-thread masks of my triangles that proposed a flip / own a winning edge
+    static_assert(PB_THREADS <= 8 * (PB_MAX_ROWS + 2), "the winner masks reuse the row tables");
+    uint32_t* pmask = (uint32_t*)scan;                           // [PB_THREADS]
+    uint32_t* wmask = (uint32_t*)rowstart;                       // [PB_THREADS]
     const unsigned off_big = ((unsigned)(PB_THREADS + 8 + 8 * (PB_MAX_ROWS + 2)) * 4u + 15u) & ~15u;
-    uint32_t* keys = (uint32_t*)(lds_raw + off_big);
     uint32_t* pts = (uint32_t*)(lds_raw + off_big);
     // one 16-B record per triangle: vertices h[0..3), neighbours across the edge opposite each vertex h[3..6), claim word
     const unsigned off_tr = (off_big + 4u * (unsigned)A.Pcap + 15u) & ~15u;
@@ -174,49 +244,90 @@ pattern_build_kernel(const PatBuildArgs A) {
     } else {
         const uint64_t pid = A.pattern_ids[j];
         const RngKey key{(uint32_t)A.seed, (uint32_t)(A.seed >> 32), (uint32_t)pid, (uint32_t)(pid >> 32)};
-        for (int q = tid; q < (G + 3) / 4; q += PB_THREADS) {                 // one Philox call keys four elements
-            const u32x4 w = draw(key, STREAM_PATTERN, (uint32_t)q);
-            const int g = 4 * q;
-            keys[g] = w.x;
-            if (g + 1 < G) keys[g + 1] = w.y;
-            if (g + 2 < G) keys[g + 2] = w.z;
-            if (g + 3 < G) keys[g + 3] = w.w;
+        // The P smallest keys by ONE histogram over the keys' top 12 bits: everything in a bin below the bin that holds the
+        // P-th smallest key is a pilot, and that bin's few elements (G / 4096 on average) are ranked exactly by (key, element).
+        // Keys are recomputed in the second pass (a Philox call keys four elements; 9 calls per thread and pass at 14 x 599) instead
+        // of being kept in LDS: the selection then needs 18 KB whatever the grid size (a key array is 4 G bytes = 33.5 KB
+        // at 14 x 599, which capped sparse patterns at four workgroups per CU).
+        uint32_t* bins = (uint32_t*)(lds_raw + off_big);                       // [SEL_BINS]
+        uint32_t* lst = bins + SEL_BINS;                                       // [SEL_LIST][2]: (key, element) of the threshold bin
+        const int nq = (G + 3) >> 2;
+        const int qper = (nq + PB_THREADS - 1) / PB_THREADS;
+        const int q_lo = min(nq, tid * qper), q_hi = min(nq, q_lo + qper);     // contiguous elements 4 q_lo ... 4 q_hi - 1
+        auto for_my_keys = [&](auto&& f) {                                     // f(key, element) in element order
+            for (int q = q_lo; q < q_hi; ++q) {
+                const u32x4 w = draw(key, STREAM_PATTERN, (uint32_t)q);
+                const int g = 4 * q;
+                f(w.x, g);
+                if (g + 1 < G) f(w.y, g + 1);
+                if (g + 2 < G) f(w.z, g + 2);
+                if (g + 3 < G) f(w.w, g + 3);
+            }
+        };
+        for (int b = tid; b < SEL_BINS; b += PB_THREADS) bins[b] = 0;
+        if (tid == 0) cnt_s[5] = 0;
+        __syncthreads();
+        for_my_keys([&](uint32_t k, int) { atomicAdd(&bins[k >> SEL_SHIFT], 1u); });
+        __syncthreads();
+        constexpr int BPT = SEL_BINS / 256;                                    // bins per scanning thread
+        int h = 0;
+        if (tid < 256) for (int i = 0; i < BPT; ++i) h += (int)bins[tid * BPT + i];
+        const int2 ex = block_exscan(h, scan);                                 // keys in lower bin groups
+        if (tid < 256 && ex.x < P && P <= ex.x + h) {                          // exactly one group qualifies
+            int acc = ex.x;
+            for (int i = 0; i < BPT; ++i) {
+                const int c = (int)bins[tid * BPT + i];
+                if (P <= acc + c) { cnt_s[0] = tid * BPT + i; cnt_s[4] = P - acc; break; }
+                acc += c;
+            }
         }
         __syncthreads();
-        // tau = the P-th smallest key, by radix selection: four passes over 8-bit digits, most significant first; each pass
-        // histograms the digit of the keys that match the prefix found so far (LDS atomics), scans the 256 bins and keeps
-        // the bin in which the P-th key falls
-        uint32_t prefix = 0;
-        int need = P;                                                         // rank of tau among the keys matching the prefix
-        for (int shift = 24; shift >= 0; shift -= 8) {
-            if (tid < 256) scan[tid] = 0;                                     // 256 bins
-            __syncthreads();
-            for (int g = g_lo; g < g_hi; ++g) {
-                const uint32_t kq = keys[g];
-                if (shift == 24 || (kq >> (shift + 8)) == prefix) atomicAdd(&scan[(kq >> shift) & 255u], 1);
+        const uint32_t tb = (uint32_t)cnt_s[0];                                // threshold bin
+        const int need = cnt_s[4];                                             // pilots to take from it (>= 1)
+        // second pass: count my elements below the threshold bin, list those inside it; where a thread's block has at most 64
+        // elements (grids up to 16 384 elements) their classification is kept as two bit masks and the third pass needs no keys
+        const bool masked = 4 * qper <= 64;
+        int nl = 0;
+        uint64_t m_lt = 0, m_eq = 0;
+        for_my_keys([&](uint32_t k, int g) {
+            const uint32_t b = k >> SEL_SHIFT;
+            nl += b < tb ? 1 : 0;
+            const uint64_t bit = 1ull << ((g - 4 * q_lo) & 63);
+            if (b < tb) m_lt |= bit;
+            if (b == tb) {
+                m_eq |= bit;
+                const int at = atomicAdd(&cnt_s[5], 1);
+                if (at < SEL_LIST) { lst[2 * at] = k; lst[2 * at + 1] = (uint32_t)g; }
             }
-            __syncthreads();
-            const int h = tid < 256 ? scan[tid] : 0;
-            __syncthreads();
-            const int2 ex = block_exscan(h, scan);                            // keys in lower bins
-            if (ex.x < need && need <= ex.x + h) { cnt_s[0] = tid; cnt_s[4] = need - ex.x; }     // exactly one bin qualifies
-            __syncthreads();
-            prefix = (prefix << 8) | (uint32_t)cnt_s[0];
-            need = cnt_s[4];
-            __syncthreads();
+        });
+        __syncthreads();
+        const int nlist = cnt_s[5];
+        if (nlist > SEL_LIST) { if (tid == 0) atomicExch(A.status, 1); return; }   // not reached with uniform keys (uniform exit)
+        // an element of the threshold bin is a pilot iff fewer than `need` of the bin's elements precede it in (key, element) order
+        auto taken = [&](uint32_t k, int g) -> bool {
+            int before = 0;
+            for (int e = 0; e < nlist; ++e) {
+                const uint32_t ke = lst[2 * e], ge = lst[2 * e + 1];
+                before += (ke < k || (ke == k && ge < (uint32_t)g)) ? 1 : 0;
+            }
+            return before < need;
+        };
+        int mine = nl;
+        uint64_t m_take = m_lt;
+        for (int e = 0; e < nlist; ++e) {
+            const int ge = (int)lst[2 * e + 1];
+            if (ge >= 4 * q_lo && ge < 4 * q_hi && taken(lst[2 * e], ge)) { ++mine; m_take |= 1ull << ((ge - 4 * q_lo) & 63); }
         }
-        const uint32_t tau = prefix;
-        int nl = 0, ne = 0;
-        for (int g = g_lo; g < g_hi; ++g) { nl += keys[g] < tau ? 1 : 0; ne += keys[g] == tau ? 1 : 0; }
-        const int2 sl = block_exscan(nl, scan);
-        const int2 se = block_exscan(ne, scan);
-        const int need_eq = P - sl.y;                                         // keys equal to tau to take, in element order
-        int pos = sl.x + min(se.x, need_eq), eq_seen = se.x;
-        for (int g = g_lo; g < g_hi; ++g) {
-            const uint32_t kq = keys[g];
-            bool take = kq < tau;
-            if (kq == tau) { take = eq_seen < need_eq; ++eq_seen; }
-            if (take) pil[pos++] = g;
+        (void)m_eq;
+        const int2 sp = block_exscan(mine, scan);
+        int pos = sp.x;
+        if (masked) {
+            for (uint64_t mm = m_take; mm != 0; mm &= mm - 1) pil[pos++] = 4 * q_lo + (__ffsll((long long)mm) - 1);
+        } else {
+            for_my_keys([&](uint32_t k, int g) {
+                const uint32_t b = k >> SEL_SHIFT;
+                if (b < tb || (b == tb && taken(k, g))) pil[pos++] = g;
+            });
         }
         __threadfence_block();
     }
@@ -230,16 +341,28 @@ pattern_build_kernel(const PatBuildArgs A) {
 
     PSTAMP(0);                                                   // pilot selection
     // ================= 2. slot table ==============================================================================
+    // Assembled in LDS (the triangle area is still free) and written out as whole 16-B vectors: a thread's own elements are
+    // consecutive, so direct 2-byte stores would touch a different cache line from every lane.
     {
+        const unsigned big_bytes = (unsigned)max((size_t)4 * A.Pcap + 16 + (size_t)2 * A.Pcap * (sizeof(TriRec) + 2), (size_t)4 * (SEL_BINS + 2 * SEL_LIST));
+        const bool staged = 2u * (unsigned)G + 16u <= big_bytes - (off_tr - off_big);     // uniform
+        uint16_t* __restrict__ stg = (uint16_t*)(lds_raw + off_tr);
         int g = g_lo;
         int s = g / nsc, k = g - s * nsc;
         int pos = g < g_hi ? count_less(pts, P, ((uint32_t)s << 16) | (uint32_t)k) : 0;      // pilots before the block
         uint32_t nextp = pos < P ? pts[pos] : 0xFFFFFFFFu;
         for (; g < g_hi; ++g) {
             const uint32_t key = ((uint32_t)s << 16) | (uint32_t)k;
-            if (key == nextp) { slotp[g] = (uint16_t)pos; ++pos; nextp = pos < P ? pts[pos] : 0xFFFFFFFFu; }
-            else slotp[g] = (uint16_t)(P + (g - pos));
+            uint16_t v;
+            if (key == nextp) { v = (uint16_t)pos; ++pos; nextp = pos < P ? pts[pos] : 0xFFFFFFFFu; }
+            else v = (uint16_t)(P + (g - pos));
+            if (staged) stg[g] = v; else slotp[g] = v;
             if (++k == nsc) { k = 0; ++s; }
+        }
+        if (staged) {
+            __syncthreads();
+            const int nvec = (2 * G + 15) >> 4;                  // the slot region of a block is padded to 16 B
+            for (int v = tid; v < nvec; v += PB_THREADS) ((uint4*)slotp)[v] = ((const uint4*)stg)[v];
         }
     }
     PSTAMP(1);                                                   // slot table
@@ -284,50 +407,44 @@ pattern_build_kernel(const PatBuildArgs A) {
     PSTAMP(2);                                                   // row tables
     const int nstrip = cnt_s[2];
     // every pilot emits the triangle that advances from it to its right-hand neighbour in its row: once as a point of the
-    // upper row of the strip below it (A-step) and once as a point of the lower row of the strip above it (B-step)
+    // upper row of the strip below it (A-step) and once as a point of the lower row of the strip above it (B-step).
+    // Merge rule = the Delaunay triangulation of the two rows alone: the apex of a row edge is the pilot of the other row
+    // nearest to the edge's midpoint, i.e. an A-step over (a_i, a_i+1) comes after exactly the B-steps whose edge midpoint lies
+    // to its left (ties: the upper row first).  Compared with merging by column this start is 17 % of the flips and a
+    // quarter of the flip rounds closer to the Delaunay triangulation (tools/delaunay_model.py).
     for (int p = tid; p < P; p += PB_THREADS) {
         const int r = px_of(pts[p]);
         int q = 0;
         while (occ[q] != r) ++q;                                 // occupied-row index (<= S steps)
         const int a0 = rowstart[r], na = rowstart[r + 1] - a0, i = p - a0;
         if (i + 1 >= na) continue;                               // last point of its row: no step starts here
-        const uint32_t nextcol = (uint32_t)py_of(pts[p + 1]);
-        if (q + 1 < m) {
-            // A-step of strip q: triangle (a_i, b_j, a_{i+1}), j = B-steps taken before = #{j' >= 1 : colB[j'] < col(a_{i+1})}
+        const int esum = py_of(pts[p]) + py_of(pts[p + 1]);      // twice the midpoint column of the edge (p, p + 1)
+        int jb = 0, ia = 0;
+        if (q + 1 < m) {                                         // B-steps of strip q before the A-step over this edge
             const int rb = occ[q + 1], b0 = rowstart[rb], nb = rowstart[rb + 1] - b0;
-            const uint32_t kb = ((uint32_t)rb << 16) | nextcol;
-            const int jb = count_less(pts + b0, nb, kb) - ((pts[b0] < kb) ? 1 : 0);
+            jb = count_pairsum_less(pts + b0, nb, esum);
+        }
+        if (q > 0) {                                             // A-steps of strip q - 1 before the B-step over this edge
+            const int ru = occ[q - 1], u0 = rowstart[ru], nu = rowstart[ru + 1] - u0;
+            ia = count_pairsum_leq(pts + u0, nu, esum);
+        }
+        if (q + 1 < m) {
+            // A-step of strip q: triangle (a_i, b_j, a_{i+1}), j = B-steps taken before
+            const int rb = occ[q + 1], b0 = rowstart[rb], nb = rowstart[rb + 1] - b0;
             const int k = i + jb, t = toff[q] + k, nq = na + nb - 2;
-            TR[t].h[0] = (uint16_t)p; TR[t].h[1] = (uint16_t)(b0 + jb); TR[t].h[2] = (uint16_t)(p + 1);
-            TR[t].h[3] = (uint16_t)(k + 1 < nq ? t + 1 : TNONE);     // rung after the step
-            TR[t].h[5] = (uint16_t)(k > 0 ? t - 1 : TNONE);          // rung before the step
-            // across the row edge: the B-step of the strip above that advances over the same edge
-            uint32_t up = TNONE;
-            if (q > 0) {
-                const int ru = occ[q - 1], u0 = rowstart[ru], nu = rowstart[ru + 1] - u0;
-                const uint32_t ku = ((uint32_t)ru << 16) | nextcol;
-                const int ia = count_leq(pts + u0, nu, ku) - ((pts[u0] <= ku) ? 1 : 0);     // A-steps before it (ties: upper row first)
-                up = (uint32_t)(toff[q - 1] + i + ia);
-            }
-            TR[t].h[4] = (uint16_t)up;
+            st_tri(TR, (uint32_t)t, (uint32_t)p, (uint32_t)(b0 + jb), (uint32_t)(p + 1),
+                   (uint32_t)(k + 1 < nq ? t + 1 : TNONE),                      // rung after the step
+                   q > 0 ? (uint32_t)(toff[q - 1] + i + ia) : TNONE,            // across the row edge: the B-step of the strip above over the same edge
+                   (uint32_t)(k > 0 ? t - 1 : TNONE), 0u);                      // rung before the step
         }
         if (q > 0) {
-            // B-step of strip q-1: triangle (b_j, b_{j+1}, a_i) with j = i here, i_A = #{i' >= 1 : colA[i'] <= col(b_{j+1})}
+            // B-step of strip q-1: triangle (b_j, b_{j+1}, a_i) with j = i here
             const int ru = occ[q - 1], u0 = rowstart[ru], nu = rowstart[ru + 1] - u0;
-            const uint32_t ku = ((uint32_t)ru << 16) | nextcol;
-            const int ia = count_leq(pts + u0, nu, ku) - ((pts[u0] <= ku) ? 1 : 0);
             const int k = i + ia, t = toff[q - 1] + k, nq = nu + na - 2;
-            TR[t].h[0] = (uint16_t)p; TR[t].h[1] = (uint16_t)(p + 1); TR[t].h[2] = (uint16_t)(u0 + ia);
-            TR[t].h[3] = (uint16_t)(k + 1 < nq ? t + 1 : TNONE);     // rung after
-            TR[t].h[4] = (uint16_t)(k > 0 ? t - 1 : TNONE);          // rung before
-            uint32_t dn = TNONE;
-            if (q + 1 < m) {
-                const int rb = occ[q + 1], b0 = rowstart[rb], nb = rowstart[rb + 1] - b0;
-                const uint32_t kb = ((uint32_t)rb << 16) | nextcol;
-                const int jb = count_less(pts + b0, nb, kb) - ((pts[b0] < kb) ? 1 : 0);
-                dn = (uint32_t)(toff[q] + i + jb);
-            }
-            TR[t].h[5] = (uint16_t)dn;
+            st_tri(TR, (uint32_t)t, (uint32_t)p, (uint32_t)(p + 1), (uint32_t)(u0 + ia),
+                   (uint32_t)(k + 1 < nq ? t + 1 : TNONE),                      // rung after
+                   (uint32_t)(k > 0 ? t - 1 : TNONE),                           // rung before
+                   q + 1 < m ? (uint32_t)(toff[q] + i + jb) : TNONE, 0u);       // across the row edge: the A-step of the strip below
         }
     }
     __syncthreads();
@@ -404,8 +521,11 @@ pattern_build_kernel(const PatBuildArgs A) {
     // two active triangles from the smaller index -- so once the bulk of the flips is done a round costs one cheap pass.
     // Every thread keeps the active set of its own triangles (t = tid + 256 i) as a register bit mask.
     constexpr uint32_t CLAIM_NONE = 0xFFFFFFFFu, CLAIM_DIRTY = 0xFFFFFFFEu;
+    const int lane = tid & 63, wbase = tid & ~63;
     uint32_t active = 0;
     for (int i = 0, t = tid; t < ntri; t += PB_THREADS, ++i) { TR[t].claim = CLAIM_DIRTY; partner[t] = (uint16_t)TNONE; active |= 1u << i; }
+    pmask[tid] = 0; wmask[tid] = 0;
+    if (tid == 0) cnt_s[3] = 0;
     __syncthreads();
 #ifdef CHEST_STAMPS
     unsigned dbg_rounds = 0, dbg_cross = 0;
@@ -414,18 +534,16 @@ pattern_build_kernel(const PatBuildArgs A) {
 #else
 #define DBG_PH(i) do { } while (0)
 #endif
+    // The triangles of a thread are t = tid + PB_THREADS * bit; in every phase the wave's work items are dealt evenly to its
+    // lanes (wave_balanced), whoever owns them.
     for (int round = 0; round < 4 * NT + 64; ++round) {
 #ifdef CHEST_STAMPS
         ++dbg_rounds;
 #endif
-        if (tid == 0) cnt_s[3] = 0;
-        __syncthreads();
         // phase 0: active triangles test their edges; an edge that fails the in-circle test claims both of its triangles.
         // One 16-B read brings a triangle; the three neighbours and then the three opposite pilots are fetched together.
-        uint32_t prop = 0;                                       // my triangles that proposed a flip this round
-        for (uint32_t m = active; m != 0; m &= m - 1) {
-            const int bit = __ffs(m) - 1;
-            const int t = tid + PB_THREADS * bit;
+        wave_balanced(active, lane, [&](int owner, int bit) {
+            const int t = wbase + owner + PB_THREADS * bit;
             const TriU T0 = ld_tri(TR, (uint32_t)t);
             const uint32_t pv[3] = {pts[T0.v[0]], pts[T0.v[1]], pts[T0.v[2]]};
             TriU U[3];
@@ -441,50 +559,50 @@ pattern_build_kernel(const PatBuildArgs A) {
                 const uint32_t d = (U[i].v[0] != b && U[i].v[0] != c) ? U[i].v[0] : ((U[i].v[1] != b && U[i].v[1] != c) ? U[i].v[1] : U[i].v[2]);
                 pd[i] = pts[need[i] ? d : T0.v[i]];
             }
+            bool proposed = false;
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
                 if (need[i] && incircle(pv[i], pv[(i + 1) % 3], pv[(i + 2) % 3], pd[i]) > 0) {
                     const uint32_t key = (uint32_t)t * 4u + (uint32_t)i;
                     atomicMin(&TR[t].claim, key);
                     atomicMin(&TR[T0.n[i]].claim, key);
-                    cnt_s[3] = 1;
-                    prop |= 1u << bit;
+                    proposed = true;
                 }
             }
-        }
+            if (proposed) { atomicOr(&pmask[wbase + owner], 1u << bit); cnt_s[3] = 1; }
+        });
         __syncthreads();
         DBG_PH(0);
         if (cnt_s[3] == 0) break;
         // phase 1: winners (an edge that holds the claim on both of its triangles) rewrite the two triangles; outer neighbours
         // keep their OLD ids for now.  Only triangles that proposed can own a winning edge.
-        uint32_t won = 0;
-        for (uint32_t m = prop; m != 0; m &= m - 1) {
-            const int bit = __ffs(m) - 1;
-            const int t = tid + PB_THREADS * bit;
+        wave_balanced(pmask[tid], lane, [&](int owner, int bit) {
+            const int t = wbase + owner + PB_THREADS * bit;
             const TriU T0 = ld_tri(TR, (uint32_t)t);
             const uint32_t key = T0.claim;
-            if ((key >> 2) != (uint32_t)t) continue;             // the winning edge of t was tested from another triangle
+            if ((key >> 2) != (uint32_t)t) return;               // the winning edge of t was tested from another triangle
+            // (run-time subscripts into the register copies of a record would put them in scratch memory: selects instead)
             const int i = (int)(key & 3u);
-            const uint32_t u = T0.n[i];
+            const uint32_t u = sel3(T0.n, i);
             const TriU U0 = ld_tri(TR, u);
-            if (U0.claim != key) continue;
-            const uint32_t a = T0.v[i], b = T0.v[(i + 1) % 3], c = T0.v[(i + 2) % 3];
-            const uint32_t n_ab = T0.n[(i + 2) % 3], n_ca = T0.n[(i + 1) % 3];
+            if (U0.claim != key) return;
+            const uint32_t a = sel3(T0.v, i), b = sel3(T0.v, i + 1), c = sel3(T0.v, i + 2);
+            const uint32_t n_ab = sel3(T0.n, i + 2), n_ca = sel3(T0.n, i + 1);
             const int jd = (U0.v[0] != b && U0.v[0] != c) ? 0 : ((U0.v[1] != b && U0.v[1] != c) ? 1 : 2);
-            const uint32_t d = U0.v[jd];
+            const uint32_t d = sel3(U0.v, jd);
             // u = (d, c, b) rotated so that u[jd] = d: the edge opposite c is (b, d), the edge opposite b is (d, c)
-            const uint32_t n_db = U0.n[(jd + 1) % 3], n_cd = U0.n[(jd + 2) % 3];
+            const uint32_t n_db = sel3(U0.n, jd + 1), n_cd = sel3(U0.n, jd + 2);
             st_tri(TR, (uint32_t)t, a, b, d, n_db, u, n_ab, key);
             st_tri(TR, u, a, d, c, n_cd, n_ca, (uint32_t)t, key);
             partner[t] = (uint16_t)u; partner[u] = (uint16_t)t;
-            won |= 1u << bit;
-        }
+            atomicOr(&wmask[wbase + owner], 1u << bit);
+        });
         __syncthreads();
         DBG_PH(1);
         // phase 2: the owner of every flip resolves the outer neighbours of its two new triangles (the old neighbour, or its
         // partner if that one flipped too) and writes the back-pointer of neighbours that did not flip
-        for (uint32_t m = won; m != 0; m &= m - 1) {
-            const int t = tid + PB_THREADS * (__ffs(m) - 1);
+        wave_balanced(wmask[tid], lane, [&](int owner, int bit) {
+            const int t = wbase + owner + PB_THREADS * bit;
             const uint32_t pT = partner[t];
 #pragma unroll
             for (int side = 0; side < 2; ++side) {
@@ -515,7 +633,7 @@ pattern_build_kernel(const PatBuildArgs A) {
                     }
                 }
             }
-        }
+        });
         __syncthreads();
         DBG_PH(2);
         // claimed triangles (flipped, or candidates that lost) are the next round's active set; marks that drew no claim clear
@@ -528,6 +646,8 @@ pattern_build_kernel(const PatBuildArgs A) {
             partner[t] = (uint16_t)TNONE;
             if (act) active |= 1u << i;
         }
+        pmask[tid] = 0; wmask[tid] = 0;
+        if (tid == 0) cnt_s[3] = 0;
         __syncthreads();
         DBG_PH(3);
     }
@@ -617,7 +737,11 @@ pattern_build_kernel(const PatBuildArgs A) {
                     }
                 }
             }
+#ifdef CHEST_EXP_NOPLAN
+            if (rec.w0 == 123.f) plan[g] = rec;
+#else
             plan[g] = rec;
+#endif
             ++g; since = 0;
             if (++k == nsc) {                                     // next row: far from here, start again from the layout guess
                 k = 0; ++s;

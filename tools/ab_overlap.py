@@ -1,0 +1,91 @@
+#!/usr/bin/env python3
+"""Per-frame pilot patterns: does building chunk c+1's patterns on a second stream while chunk c's frames run shorten the step?
+
+    python tools/ab_overlap.py [--frames 10000] [--chunks 1,2,4,8] [--reps 7]
+
+A step = build F patterns (selection + Delaunay + plan) + run F frames (cfg2 shape, all seven outputs).  chunks = 1 is the
+serial order on one stream (what bench.py --pattern-group 1 times); chunks = C splits the batch into C contiguous ranges, builds
+range c on stream A and runs its frames on stream B behind an event.  Wall time per step from events on the current stream.
+"""
+import argparse
+import importlib
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+PKG = "channel-estimation-in-5g-network_amd"
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--frames", type=int, default=10000)
+    ap.add_argument("--chunks", default="1,2,4,8,16")
+    ap.add_argument("--reps", type=int, default=7)
+    ap.add_argument("--serial", action="store_true", help="chunks on ONE stream: build c, frames c, build c+1, ... (cache-residency test)")
+    args = ap.parse_args()
+    import torch
+    E = importlib.import_module(PKG + ".engine")
+    F = args.frames
+    geom = E.Geometry(num_tx=2, num_rx=2)
+    names = ["tx", "rx", "H", "H_ls", "H_mmse", "pilot_symbols", "pilot_mask"]
+    G = geom.grid
+    P = int(G * 0.1)
+    for C in [int(c) for c in args.chunks.split(",")]:
+        eng = E.Engine(geom, 0)
+        bounds = [(F * c // C, F * (c + 1) // C) for c in range(C)]
+        npil = np.full(F, P, np.int32)
+        ids = np.arange(F, dtype=np.uint64)
+        for c0, c1 in bounds:                                    # one pool per chunk: rebuilt in place afterwards
+            eng.build_patterns(c0, npil[c0:c1], seed=2024, pattern_ids=ids[c0:c1], method="linear")
+        descs = E.make_descs("EVA", 111.1, 10.0, np.arange(F, dtype=np.int32), n=F)
+        d_dev = torch.from_numpy(descs.view(np.uint8).copy()).to(eng.device).view(F, -1)
+        out = eng.run_frames(d_dev.view(-1), seed=1, outputs=names)
+        sA, sB = torch.cuda.Stream(), torch.cuda.Stream()
+        main_s = torch.cuda.current_stream()
+
+        def step():
+            if C == 1:
+                eng.build_patterns(0, npil, seed=2024, pattern_ids=ids, method="linear")
+                eng.run_frames(d_dev.view(-1), seed=1, outputs=names, out=out, check=False)
+                return
+            if args.serial:
+                for c0, c1 in bounds:
+                    eng.build_patterns(c0, npil[c0:c1], seed=2024, pattern_ids=ids[c0:c1], method="linear")
+                    eng.run_frames(d_dev[c0:c1].reshape(-1), seed=1, frame_offset=c0, outputs=names,
+                                   out={k: v[c0:c1] for k, v in out.items()}, check=False)
+                return
+            sA.wait_stream(main_s); sB.wait_stream(main_s)
+            for c0, c1 in bounds:
+                with torch.cuda.stream(sA):
+                    eng.build_patterns(c0, npil[c0:c1], seed=2024, pattern_ids=ids[c0:c1], method="linear")
+                    ev = torch.cuda.Event(); ev.record()
+                with torch.cuda.stream(sB):
+                    sB.wait_event(ev)
+                    eng.run_frames(d_dev[c0:c1].reshape(-1), seed=1, frame_offset=c0, outputs=names,
+                                   out={k: v[c0:c1] for k, v in out.items()}, check=False)
+            main_s.wait_stream(sA); main_s.wait_stream(sB)
+
+        ts = []
+        for rep in range(args.reps + 2):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(); step(); b.record()
+            torch.cuda.synchronize()
+            if rep >= 2:
+                ts.append(a.elapsed_time(b))
+        eng.check_status()
+        eng.profile_begin(2 * C)
+        step()
+        kern = eng.profile_read_all()
+        eng.profile_begin(0)
+        print("   per-launch kernel ms:", {k: round(v, 3) for k, v in kern.items()}, flush=True)
+        m = float(np.median(ts))
+        print(f"chunks {C:3d}: step {m:.3f} ms (min {min(ts):.3f})  = {F / m / 1e3:.3f} M frames/s", flush=True)
+        del out, eng
+        torch.cuda.empty_cache()
+
+
+if __name__ == "__main__":
+    main()

@@ -2,7 +2,7 @@
 """CPU model of the on-device Delaunay construction for lattice pilots (csrc/pattern_kernels.hip follows it step by step):
 
   1. initial triangulation: pilots lie on S parallel rows; every strip between two consecutive occupied rows is triangulated
-     by merging the two sorted rows (rank arithmetic only: every triangle and its three neighbours are computed
+     by merging the two sorted rows by edge midpoint = their two-row Delaunay triangulation (rank arithmetic only: every triangle and its three neighbours are computed
      independently), and the pockets between the left / right end chains and the convex hull are filled by a monotone-chain
      scan (a handful of triangles);
   2. Lawson flips with the EXACT integer in-circle test until every interior edge is locally Delaunay, in rounds of
@@ -47,8 +47,9 @@ def initial_triangulation(px, py):
         i, j = start[ra], start[rb]
         ia, jb = end[ra] - 1, end[rb] - 1
         while i < ia or j < jb:
-            # advance the row whose next point has the smaller column (ties: the upper row); exhausted rows cannot advance
-            if j >= jb or (i < ia and py[i + 1] <= py[j + 1]):
+            # the Delaunay triangulation of the two rows alone: advance the row whose next edge has its midpoint further left
+            # (ties: the upper row); exhausted rows cannot advance
+            if j >= jb or (i < ia and py[i] + py[i + 1] <= py[j] + py[j + 1]):
                 add(i, i + 1, j); i += 1
             else:
                 add(j, j + 1, i); j += 1
