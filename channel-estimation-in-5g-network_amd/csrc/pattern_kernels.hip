@@ -856,7 +856,7 @@ extern "C" int chest_patterns_build(chest_ctx* ctx, void* stream, int32_t first_
     a.first_slot = first_slot; a.S = ctx->fp.S; a.nsc = ctx->fp.nsc; a.method = method; a.Pcap = pool->Pcap;
     a.simp_out = simplices_out; a.nbr_out = simplices_out ? neighbors_out : nullptr; a.nsimp_out = num_simplices_out; a.status = ctx->d_status;
     if (simplices_out && pool->Pcap != Pmax) { set_error("chest_patterns_build: simplices_out needs a fresh slot range (row stride is 2*Pmax*3)"); return CHEST_EINVAL; }
-    const size_t lds_run = pattern_build_lds_bytes(G, pool->Pcap);
+    const size_t lds_run = pattern_build_lds_bytes(G, pool->Pcap) + (size_t)ctx->tune_pattern_extra_lds;
     CHEST_LDS_OPT_IN(ctx, LDS_DELAUNAY, pattern_build_kernel, lds_run);
     const int sp = prof_open(ctx, st, CHEST_K_PLAN);
     hipLaunchKernelGGL(pattern_build_kernel, dim3((unsigned)count), dim3(PB_THREADS), lds_run, st, a);

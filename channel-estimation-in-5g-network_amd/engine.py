@@ -267,7 +267,7 @@ class Engine:
         return res
 
     def tune(self, key: str, value: int):
-        """Experiment knobs of the library (tools only): 'frame_rx_group', 'frame_legacy_rows'."""
+        """Experiment knobs of the library (tools only): 'frame_rx_group', 'frame_min_waves', 'pattern_extra_lds'."""
         N.check(N.lib().chest_tune(self._h, key.encode(), int(value)), "chest_tune")
 
     # ---- helpers ----------------------------------------------------------------------------------

@@ -197,7 +197,8 @@ int chest_profile_read_kernel(chest_ctx* ctx, int32_t kernel_id, float* ms, int3
 
 /* Tuning knobs for experiments (tools/ only; the launch path reads nothing from the environment).  Keys:
  *   "frame_rx_group"   rx antennas per LDS slab unit of the frame kernel (0 = chosen from the LDS budget)
- *   "frame_min_waves"  4 = the 128-VGPR instantiation of the 2x2 frame kernel (two resident workgroups per CU instead of three) */
+ *   "frame_min_waves"  4 = the 128-VGPR instantiation of the 2x2 frame kernel (two resident workgroups per CU instead of three)
+ *   "pattern_extra_lds" bytes of unused LDS added to the pattern kernel's allocation (workgroups-per-CU experiments) */
 int chest_tune(chest_ctx* ctx, const char* key, int32_t value);
 
 /* ---- launch group (asynchronous, no allocation) -------------------------------------------- */

@@ -196,10 +196,12 @@ def test_device_clough_tocher_operator_equals_scipy_on_qhulls_triangulation(U, d
     simp, nbr = IP.delaunay_with_neighbors(ps, pk)
     slot = eng.pattern_slot(idx, "linear", plan=simp)
     A = eng.cubic_operator_from_triangulation(slot, simp, nbr)
-    t0 = time.perf_counter()
-    A = eng.cubic_operator_from_triangulation(slot, simp, nbr)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    dt = 1e9
+    for _ in range(3):                                            # best of three: the host side of a shared box stalls now and then
+        t0 = time.perf_counter()
+        A = eng.cubic_operator_from_triangulation(slot, simp, nbr)
+        torch.cuda.synchronize()
+        dt = min(dt, time.perf_counter() - t0)
     ref = IP.cubic_operator(ps, pk, S, nsc)                       # SciPy's interpolator on the identity (host, ~1 s at full size)
     got = A.cpu().numpy()
     assert got.shape == ref.shape == (G, P)

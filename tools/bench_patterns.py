@@ -17,6 +17,8 @@ def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
     geom = E.Geometry()
     eng = E.Engine(geom, 0)
+    if len(sys.argv) > 2:                       # occupancy experiment: extra (unused) LDS bytes per workgroup
+        eng.tune("pattern_extra_lds", int(sys.argv[2]))
     G = geom.grid
     for dens, method in ((0.10, "linear"), (0.05, "linear"), (0.01, "linear"), (0.10, "nearest"), (0.10, None)):
         P = int(G * dens)
