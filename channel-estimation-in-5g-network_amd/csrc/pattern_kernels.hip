@@ -175,10 +175,10 @@ __device__ __forceinline__ void wave_balanced(uint32_t mask, int lane, F&& fn) {
 }
 
 size_t pattern_build_lds_bytes(int G, int Pcap) {
-    const size_t tri = (size_t)4 * Pcap + 16 + (size_t)2 * Pcap * (sizeof(uint16_t) * 6 + 4 + 2);        // pts | triangle records | partner
+    const size_t tri = (size_t)4 * Pcap + 16 + (size_t)2 * Pcap * (sizeof(uint16_t) * 6 + 4);            // pts | triangle records
     const size_t keys = (size_t)4 * (SEL_BINS + 2 * SEL_LIST);                                        // selection: histogram + threshold-bin list
     (void)G;
-    return (tri > keys ? tri : keys) + (size_t)(PB_THREADS + 8 + 8 * (PB_MAX_ROWS + 2)) * sizeof(int) + 64;
+    return (tri > keys ? tri : keys) + (size_t)(PB_THREADS + 8 + 3 * (PB_MAX_ROWS + 2)) * sizeof(int) + 64;
 }
 
 #ifdef CHEST_STAMPS
@@ -213,28 +213,25 @@ pattern_build_kernel(const PatBuildArgs A) {
 
     // ---- LDS carve-up: the key array of step 1 shares its space with the triangle arrays of steps 3-5 ----------------
     const int NT = 2 * A.Pcap;
-    int* misc = (int*)lds_raw;                                   // [PB_THREADS + 8 + 4 * (rows + 2)]
-    int* scan = misc;                                            // PB_THREADS + 1
+    int* misc = (int*)lds_raw;                                   // [PB_THREADS + 8 + 3 * (rows + 2)]
+    int* scan = misc;                                            // PB_THREADS + 1: workgroup scans of the pilot selection, then
     int* cnt_s = misc + PB_THREADS + 1;                          // a few scalars
     int* rowstart = misc + PB_THREADS + 8;                       // [rows + 1] first pilot of every row
     int* occ = rowstart + PB_MAX_ROWS + 2;                       // occupied rows
     int* toff = occ + PB_MAX_ROWS + 2;                           // first triangle of every strip
-    int* stack = toff + PB_MAX_ROWS + 2;                         // pocket scan (thread 0): chain stack,
+    static_assert(4 * (PB_MAX_ROWS + 2) <= PB_THREADS, "the pocket scan's arrays live in the scan area");
+    int* stack = scan;                                           // ... the pocket scan (thread 0): chain stack,
     uint32_t* eown = (uint32_t*)(stack + PB_MAX_ROWS + 2);       //   owner of the edge (stack[i-1], stack[i]): tri << 2 | slot, or ~0u,
     int* eq = (int*)(eown + PB_MAX_ROWS + 2);                    //   strip of that edge if it is the bare chain edge of a strip without triangles,
     uint32_t* rung = (uint32_t*)(eq + PB_MAX_ROWS + 2);          //   and who owns such an edge after the left pass
+    uint32_t* pmask = (uint32_t*)scan;                           // ... and in the flip rounds [PB_THREADS]: my triangles that proposed a flip
     // (byte offsets from the LDS base, never pointer -> integer -> pointer: such a round trip loses the LDS address space and
     // every access below becomes a FLAT instruction)
-    // flip rounds (selection scan and row tables are dead by then): per-thread masks of my triangles that proposed a flip / own a winning edge
-    static_assert(PB_THREADS <= 8 * (PB_MAX_ROWS + 2), "the winner masks reuse the row tables");
-    uint32_t* pmask = (uint32_t*)scan;                           // [PB_THREADS]
-    uint32_t* wmask = (uint32_t*)rowstart;                       // [PB_THREADS]
-    const unsigned off_big = ((unsigned)(PB_THREADS + 8 + 8 * (PB_MAX_ROWS + 2)) * 4u + 15u) & ~15u;
+    const unsigned off_big = ((unsigned)(PB_THREADS + 8 + 3 * (PB_MAX_ROWS + 2)) * 4u + 15u) & ~15u;
     uint32_t* pts = (uint32_t*)(lds_raw + off_big);
     // one 16-B record per triangle: vertices h[0..3), neighbours across the edge opposite each vertex h[3..6), claim word
     const unsigned off_tr = (off_big + 4u * (unsigned)A.Pcap + 15u) & ~15u;
     TriRec* TR = (TriRec*)(lds_raw + off_tr);
-    uint16_t* partner = (uint16_t*)(lds_raw + off_tr + (unsigned)NT * (unsigned)sizeof(TriRec));
 
     // ================= 1. pilots =================================================================================
     const int per = (G + PB_THREADS - 1) / PB_THREADS;           // contiguous element block of this thread
@@ -344,7 +341,7 @@ pattern_build_kernel(const PatBuildArgs A) {
     // Assembled in LDS (the triangle area is still free) and written out as whole 16-B vectors: a thread's own elements are
     // consecutive, so direct 2-byte stores would touch a different cache line from every lane.
     {
-        const unsigned big_bytes = (unsigned)max((size_t)4 * A.Pcap + 16 + (size_t)2 * A.Pcap * (sizeof(TriRec) + 2), (size_t)4 * (SEL_BINS + 2 * SEL_LIST));
+        const unsigned big_bytes = (unsigned)max((size_t)4 * A.Pcap + 16 + (size_t)2 * A.Pcap * sizeof(TriRec), (size_t)4 * (SEL_BINS + 2 * SEL_LIST));
         const bool staged = 2u * (unsigned)G + 16u <= big_bytes - (off_tr - off_big);     // uniform
         uint16_t* __restrict__ stg = (uint16_t*)(lds_raw + off_tr);
         int g = g_lo;
@@ -520,11 +517,14 @@ pattern_build_kernel(const PatBuildArgs A) {
     // claim in the previous round; everything is active at first.  Only active triangles test their edges -- an edge between
     // two active triangles from the smaller index -- so once the bulk of the flips is done a round costs one cheap pass.
     // Every thread keeps the active set of its own triangles (t = tid + 256 i) as a register bit mask.
-    constexpr uint32_t CLAIM_NONE = 0xFFFFFFFFu, CLAIM_DIRTY = 0xFFFFFFFEu;
+    // claim word: CLAIM_NONE / CLAIM_DIRTY (inactive / active, unclaimed), the smallest key (4 t + edge < 2^18) of the edges that
+    // claimed the triangle, or that key | CLAIM_WON once the edge has flipped: the two triangles of a flip find each other
+    // through it (the owner t keeps its partner in neighbour slot 1, the partner keeps t in slot 2)
+    constexpr uint32_t CLAIM_NONE = 0xFFFFFFFFu, CLAIM_DIRTY = 0xFFFFFFFEu, CLAIM_WON = 0x40000000u;
     const int lane = tid & 63, wbase = tid & ~63;
     uint32_t active = 0;
-    for (int i = 0, t = tid; t < ntri; t += PB_THREADS, ++i) { TR[t].claim = CLAIM_DIRTY; partner[t] = (uint16_t)TNONE; active |= 1u << i; }
-    pmask[tid] = 0; wmask[tid] = 0;
+    for (int i = 0, t = tid; t < ntri; t += PB_THREADS, ++i) { TR[t].claim = CLAIM_DIRTY; active |= 1u << i; }
+    pmask[tid] = 0;
     if (tid == 0) cnt_s[3] = 0;
     __syncthreads();
 #ifdef CHEST_STAMPS
@@ -576,7 +576,8 @@ pattern_build_kernel(const PatBuildArgs A) {
         if (cnt_s[3] == 0) break;
         // phase 1: winners (an edge that holds the claim on both of its triangles) rewrite the two triangles; outer neighbours
         // keep their OLD ids for now.  Only triangles that proposed can own a winning edge.
-        wave_balanced(pmask[tid], lane, [&](int owner, int bit) {
+        const uint32_t proposed = pmask[tid];
+        wave_balanced(proposed, lane, [&](int owner, int bit) {
             const int t = wbase + owner + PB_THREADS * bit;
             const TriU T0 = ld_tri(TR, (uint32_t)t);
             const uint32_t key = T0.claim;
@@ -592,30 +593,37 @@ pattern_build_kernel(const PatBuildArgs A) {
             const uint32_t d = sel3(U0.v, jd);
             // u = (d, c, b) rotated so that u[jd] = d: the edge opposite c is (b, d), the edge opposite b is (d, c)
             const uint32_t n_db = sel3(U0.n, jd + 1), n_cd = sel3(U0.n, jd + 2);
-            st_tri(TR, (uint32_t)t, a, b, d, n_db, u, n_ab, key);
-            st_tri(TR, u, a, d, c, n_cd, n_ca, (uint32_t)t, key);
-            partner[t] = (uint16_t)u; partner[u] = (uint16_t)t;
-            atomicOr(&wmask[wbase + owner], 1u << bit);
+            st_tri(TR, (uint32_t)t, a, b, d, n_db, u, n_ab, key | CLAIM_WON);
+            st_tri(TR, u, a, d, c, n_cd, n_ca, (uint32_t)t, key | CLAIM_WON);
         });
         __syncthreads();
         DBG_PH(1);
         // phase 2: the owner of every flip resolves the outer neighbours of its two new triangles (the old neighbour, or its
         // partner if that one flipped too) and writes the back-pointer of neighbours that did not flip
-        wave_balanced(wmask[tid], lane, [&](int owner, int bit) {
+        uint32_t won = 0;                                        // my triangles that own a flip of this round (claim = own key | CLAIM_WON)
+        for (uint32_t m = proposed; m != 0; m &= m - 1) {
+            const int bit = __ffs(m) - 1;
+            const uint32_t c = TR[tid + PB_THREADS * bit].claim;
+            if ((c & 0xC0000000u) == CLAIM_WON && ((c & ~CLAIM_WON) >> 2) == (uint32_t)(tid + PB_THREADS * bit)) won |= 1u << bit;
+        }
+        wave_balanced(won, lane, [&](int owner, int bit) {
             const int t = wbase + owner + PB_THREADS * bit;
-            const uint32_t pT = partner[t];
+            const TriU Tt = ld_tri(TR, (uint32_t)t);
+            const uint32_t pT = Tt.n[1];
+            const TriU Tp = ld_tri(TR, pT);
 #pragma unroll
             for (int side = 0; side < 2; ++side) {
                 const uint32_t X = side == 0 ? (uint32_t)t : pT;
                 const uint32_t pX = side == 0 ? pT : (uint32_t)t;
-                const TriU TX = ld_tri(TR, X);
+                const TriU TX = side == 0 ? Tt : Tp;
                 TriU TY[3];
                 uint32_t pY[3];
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
                     const uint32_t Y = (TX.n[k] == TNONE || TX.n[k] == pX) ? X : TX.n[k];
                     TY[k] = ld_tri(TR, Y);
-                    pY[k] = partner[Y];
+                    const uint32_t cy = TY[k].claim;             // flipped in this round: its partner, else TNONE
+                    pY[k] = (cy & 0xC0000000u) == CLAIM_WON ? ((((cy & ~CLAIM_WON) >> 2) == Y) ? TY[k].n[1] : TY[k].n[2]) : TNONE;
                 }
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
@@ -643,10 +651,9 @@ pattern_build_kernel(const PatBuildArgs A) {
             if (c == CLAIM_NONE) continue;
             const bool act = c < CLAIM_DIRTY;
             TR[t].claim = act ? CLAIM_DIRTY : CLAIM_NONE;
-            partner[t] = (uint16_t)TNONE;
             if (act) active |= 1u << i;
         }
-        pmask[tid] = 0; wmask[tid] = 0;
+        pmask[tid] = 0;
         if (tid == 0) cnt_s[3] = 0;
         __syncthreads();
         DBG_PH(3);
@@ -677,10 +684,10 @@ pattern_build_kernel(const PatBuildArgs A) {
         // from a far triangle crosses hundreds of them along the 599-column axis (stamps: 407 crossings for 33 elements).
         // (the smallest incident triangle number, so that a rebuilt pattern gives the bit-identical plan: an element ON an
         // edge belongs to whichever of the two triangles the walk reaches first)
-        uint32_t* __restrict__ v2t = (uint32_t*)partner;         // partner[] (2 * Pcap uint16) is free after the flips
-        for (int i = tid; i < P; i += PB_THREADS) v2t[i] = 0xFFFFFFFFu;
+        // (kept in the claim word of record i for pilot i: the claims are dead after the flips)
+        for (int i = tid; i < P; i += PB_THREADS) TR[i].claim = 0xFFFFFFFFu;
         __syncthreads();
-        for (int t = tid; t < ntri; t += PB_THREADS) { atomicMin(&v2t[TR[t].h[0]], (uint32_t)t); atomicMin(&v2t[TR[t].h[1]], (uint32_t)t); atomicMin(&v2t[TR[t].h[2]], (uint32_t)t); }
+        for (int t = tid; t < ntri; t += PB_THREADS) { atomicMin(&TR[TR[t].h[0]].claim, (uint32_t)t); atomicMin(&TR[TR[t].h[1]].claim, (uint32_t)t); atomicMin(&TR[TR[t].h[2]].claim, (uint32_t)t); }
         __syncthreads();
         auto near_tri = [&](int s_, int k_) -> int {
             const uint32_t q = ((uint32_t)s_ << 16) | (uint32_t)k_;
@@ -692,7 +699,7 @@ pattern_build_kernel(const PatBuildArgs A) {
                 const int db = (s_ - px_of(b)) * (s_ - px_of(b)) + (k_ - py_of(b)) * (k_ - py_of(b));
                 if (da < db) --ip;
             }
-            return (int)v2t[ip];
+            return (int)TR[ip].claim;
         };
         int g = g_lo;
         int s = g / nsc, k = g - s * nsc;
