@@ -283,11 +283,12 @@ def run(args):
         dens_list = list(w["densities"])
         npil_of_density = np.asarray([int(G * d) for d in dens_list], dtype=np.int32)
         per_step_patterns = device_patterns and group == 1
+        pf_method = "linear_compact" if eng.compact_plans_supported else "linear"     # plans that are read once: the compact format
         first_group, last_group = 0, (total_steps * world * F - 1) // group
         keys = [(di, gidx) for di in range(len(dens_list)) for gidx in range(first_group, last_group + 1)] if not per_step_patterns else []
         if per_step_patterns:
             pils, slots = [], []
-            eng.build_patterns(0, np.full(F, npil_of_density.max(), np.int32), seed=seed, pattern_ids=np.arange(F, dtype=np.uint64), method="linear")   # reserves the slot range
+            eng.build_patterns(0, np.full(F, npil_of_density.max(), np.int32), seed=seed, pattern_ids=np.arange(F, dtype=np.uint64), method=pf_method)   # reserves the slot range
         elif device_patterns:
             ids = np.asarray([gidx * len(dens_list) + di for di, gidx in keys], dtype=np.uint64)
             slots = eng.build_patterns(0, npil_of_density[[di for di, _ in keys]], seed=seed, pattern_ids=ids, method="linear")
@@ -303,8 +304,10 @@ def run(args):
         # one pattern per frame: the pattern belongs to the frame (simulate_transmission draws it), so it is built inside
         # the timed step from (seed, global frame index) unless --patterns-resident asks for the plans to be pre-built
         per_step_patterns = device_patterns and group == 1 and kind == "frames" and not args.patterns_resident
+        # a pattern (and plan) per frame is read once, from HBM: the compact plan format; shared patterns stay in L2: the full one
+        pf_method = "linear_compact" if (group == 1 and kind == "frames" and eng.compact_plans_supported) else "linear"
         if device_patterns:
-            slots = eng.build_patterns(0, np.full(npat, int(G * w["dens"]), np.int32), seed=2024, pattern_ids=np.arange(npat, dtype=np.uint64), method="linear")
+            slots = eng.build_patterns(0, np.full(npat, int(G * w["dens"]), np.int32), seed=2024, pattern_ids=np.arange(npat, dtype=np.uint64), method=pf_method)
             pils = [eng.get_pilots(int(slots[0]))] if kind == "fullcov" else [None] * npat
         else:
             pils = []
@@ -350,7 +353,7 @@ def run(args):
         def dataset_step(off):
             d, (npil, ids) = descs_for(off)
             if per_step_patterns:           # every frame draws its own pilot pattern: selection + Delaunay + plan, in place
-                eng.build_patterns(0, npil, seed=seed, pattern_ids=ids, method="linear")
+                eng.build_patterns(0, npil, seed=seed, pattern_ids=ids, method=pf_method)
             return d
         d_first = dataset_step(rank * F)
     else:
@@ -398,7 +401,7 @@ def run(args):
             eng.mmse_full_apply_pilots(out["h_ls_pilots"], slots[0], W, out=out["H_mmse"], scratch=scr)
         else:
             if per_step_patterns:
-                eng.build_patterns(0, npil_frames, seed=2024, pattern_ids=np.arange(off, off + F, dtype=np.uint64), method="linear")
+                eng.build_patterns(0, npil_frames, seed=2024, pattern_ids=np.arange(off, off + F, dtype=np.uint64), method=pf_method)
             eng.run_frames(d_first, seed=seed, frame_offset=off, outputs=names, out=out, check=False)
 
     # est-MSE is evaluate_estimator's job, not part of the LS+MMSE step: one extra UNTIMED launch with the fused
@@ -468,8 +471,9 @@ def run(args):
             cfgd.update(channel=w["ct"], doppler_hz=w["fd"], snr_db=w["snr"], pilot_density=w["dens"],
                         path="simulate_transmission + LSEstimator.estimate + MMSEEstimator.estimate per frame",
                         estimators="LS(linear)+MMSE(diag)")
-        if group == 1 and kind != "fullcov":   # a plan of its own per frame has to be read: 16-B record per RE + 4-B pilot index
-            bytes_frame += 16 * G + 4 * P
+        if group == 1 and kind != "fullcov":   # a plan of its own per frame has to be read: 16-B record per RE + 4-B pilot index (SURVEY 8d row 4;
+            bytes_frame += 16 * G + 4 * P       # the compact format the engine reads instead is smaller -- the algorithmic figure stays SURVEY's)
+            cfgd["plan_format"] = pf_method
         if "plan_kernels" in kern:
             cfgd["plan_build_kernel_ms"] = kern["plan_kernels"]
         if kind == "fullcov":

@@ -328,7 +328,27 @@ int chest_pattern_get_plan(chest_ctx* ctx, int32_t slot, uint16_t* plan_idx, flo
     std::vector<Rec> recs(G);
     CHEST_GUARD(ctx);
     CHEST_HIP(hipDeviceSynchronize());
-    CHEST_HIP(hipMemcpy(recs.data(), ctx->patterns[slot].dev.plan, (size_t)G * sizeof(Rec), hipMemcpyDeviceToHost));
+    const chest::PatternDev& pd = ctx->patterns[slot].dev;
+    if (pd.pad != 0) {
+        // compact plan: expand the triangle records at every element exactly as the frame kernel does (chest_device.h: plan_rec)
+        const int ntab = pd.pad / 16 < 2 * 4096 ? pd.pad / 16 : 2 * 4096;     // the record table ends before the per-element ids
+        std::vector<uint32_t> tab((size_t)ntab * 4);
+        std::vector<uint16_t> tri(G);
+        CHEST_HIP(hipMemcpy(tab.data(), pd.plan, tab.size() * 4, hipMemcpyDeviceToHost));
+        CHEST_HIP(hipMemcpy(tri.data(), (const unsigned char*)pd.plan + pd.pad, (size_t)G * 2, hipMemcpyDeviceToHost));
+        const int nsc = ctx->fp.nsc;
+        for (int g = 0; g < G; ++g) {
+            const uint32_t* d = &tab[(size_t)(tri[g] < ntab ? tri[g] : 0) * 4];
+            const int s = g / nsc, k = g - s * nsc;
+            const int pa = (int)(d[1] >> 16), pb = (int)(d[2] & 0xFFFFu), pc = (int)(d[2] >> 16);
+            const int ax = pa >> 11, ay = pa & 0x7FF, bx = pb >> 11, by = pb & 0x7FF, cx = pc >> 11, cy = pc & 0x7FF;
+            const int o0 = (cx - bx) * (k - by) - (cy - by) * (s - bx), o1 = (ax - cx) * (k - cy) - (ay - cy) * (s - cx);
+            float rden;
+            memcpy(&rden, &d[3], 4);
+            recs[g] = Rec{(float)o0 * rden, (float)o1 * rden, d[0], (d[1] & 0xFFFFu) | (pa != 0xFFFF ? 1u << 16 : 0u)};
+        }
+    } else
+    CHEST_HIP(hipMemcpy(recs.data(), pd.plan, (size_t)G * sizeof(Rec), hipMemcpyDeviceToHost));
     for (int g = 0; g < G; ++g) {
         const Rec& r = recs[g];
         const bool valid = (r.i2v >> 16) != 0;

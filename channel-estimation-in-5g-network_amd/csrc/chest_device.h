@@ -106,6 +106,25 @@ __device__ __forceinline__ PlanRec ld_plan(gptr_plan plan, int i) {     // one 1
     return PlanRec{__uint_as_float(v.x), __uint_as_float(v.y), v.z, v.w};
 }
 
+// Compact plans (chest_patterns_build method 2): the plan names a TRIANGLE per resource element (u16) and holds one 16-B
+// record per triangle -- {i0 | i1 << 16, i2 | pa << 16, pb | pc << 16, 1 / (2 area)} with p = symbol << 11 | subcarrier of
+// the three vertices (pa = 0xFFFF: outside the hull) -- 67 KB per 14 x 599 pattern instead of 151 KB.  The reader evaluates
+// the two edge functions at its own (symbol, subcarrier): w0 = orient(b, c, q) / (2 area), w1 = orient(c, a, q) / (2 area),
+// exactly the integers the full plan's weights were divided from.  `raw` carries the record's four words in a PlanRec.
+template <bool CP>
+__device__ __forceinline__ PlanRec plan_rec(const PlanRec& raw, int s, int k) {
+    if constexpr (!CP) return raw;
+    else {
+        const uint32_t d0 = __float_as_uint(raw.w0), d1 = __float_as_uint(raw.w1), d2 = raw.i01;
+        const int pa = (int)(d1 >> 16), pb = (int)(d2 & 0xFFFFu), pc = (int)(d2 >> 16);
+        const int ax = pa >> 11, ay = pa & 0x7FF, bx = pb >> 11, by = pb & 0x7FF, cx = pc >> 11, cy = pc & 0x7FF;
+        const int o0 = (cx - bx) * (k - by) - (cy - by) * (s - bx);
+        const int o1 = (ax - cx) * (k - cy) - (ay - cy) * (s - cx);
+        const float rden = __uint_as_float(raw.i2v);             // 0 for the "outside" record
+        return PlanRec{(float)o0 * rden, (float)o1 * rden, d0, (d1 & 0xFFFFu) | (pa != 0xFFFF ? 1u << 16 : 0u)};
+    }
+}
+
 __device__ __forceinline__ float2 interp(const PlanRec& p, const float2* __restrict__ hp, int stride, int r) {
     const float w2 = (p.i2v >> 16) ? (1.0f - p.w0 - p.w1) : 0.0f;
     const float2 a0 = hp[(p.i01 & 0xFFFFu) * stride + r], a1 = hp[(p.i01 >> 16) * stride + r],

@@ -43,10 +43,10 @@ struct FrameParams {               // passed by value (kernarg segment -> scalar
 
 struct PatternDev {
     const uint16_t* slot;          // [G] draw slot of each RE: < P pilot ordinal, else P + data ordinal
-    const void* plan;              // [G] 16-B records {w0, w1, i0|i1<<16, i2|valid<<16} or nullptr
+    const void* plan;              // [G] 16-B records {w0, w1, i0|i1<<16, i2|valid<<16} or nullptr; compact plans: [2 Pcap] triangle records
     const int32_t* pilot_idx;      // [P]
     int32_t P;
-    int32_t pad;
+    int32_t pad;                   // 0, or (compact plan) the byte offset from `plan` to the u16 triangle id of every element
 };
 
 struct PatternHost {
@@ -58,7 +58,8 @@ struct PatternHost {
 // slot u16[G] | pilot_idx i32[Pcap] | plan PlanRec[G], reused in place when the same slot range is rebuilt.
 struct PatternPool {
     int32_t first_slot = 0, count = 0, Pcap = 0;
-    size_t stride = 0, o_pil = 0, o_plan = 0;
+    size_t stride = 0, o_pil = 0, o_plan = 0, o_tri = 0;
+    bool compact = false;          // plan blocks hold triangle records + per-element triangle ids (chest_patterns_build method 2)
     void* block = nullptr;
     void* d_meta = nullptr;        // per-pattern pilot counts and pattern ids on the device
 };
@@ -103,7 +104,8 @@ void set_error(const char* fmt, ...);
     } while (0)
 
 enum { LDS_TAPS = 0, LDS_FRAME = 1, LDS_ESTIMATE = 2, LDS_INTERP = 3, LDS_GEMM = 4, LDS_GEMM3M = 5, LDS_FRAME_640 = 6,
-       LDS_FRAME_1024 = 7, LDS_FRAME_ROWS = 8, LDS_DELAUNAY = 9, LDS_FRAME_44 = 10, LDS_FRAME_11 = 11, LDS_FRAME_GEN = 12, LDS_FRAME_W5 = 13, LDS_GJ_PANEL = 14, LDS_GJ_UPDATE = 15, LDS_GJ_PANEL_R = 16, LDS_GJ_UPDATE_R = 17, LDS_FRAME_640_44 = 18, LDS_INTERP_TFOLD = 19 };
+       LDS_FRAME_1024 = 7, LDS_FRAME_ROWS = 8, LDS_DELAUNAY = 9, LDS_FRAME_44 = 10, LDS_FRAME_11 = 11, LDS_FRAME_GEN = 12, LDS_FRAME_W5 = 13, LDS_GJ_PANEL = 14, LDS_GJ_UPDATE = 15, LDS_GJ_PANEL_R = 16, LDS_GJ_UPDATE_R = 17, LDS_FRAME_640_44 = 18, LDS_INTERP_TFOLD = 19,
+       LDS_FRAME_CP = 20, LDS_FRAME_44_CP = 21, LDS_FRAME_11_CP = 22, LDS_FRAME_GEN_CP = 23 };
 
 // RAII: make the context's device current for the duration of an entry point and restore the caller's afterwards
 struct DeviceGuard {
@@ -146,7 +148,7 @@ int launch_frames(chest_ctx* ctx, hipStream_t st, int32_t B, const chest_frame_d
                   int64_t workspace_bytes);
 size_t frames_workspace_bytes(const chest_ctx* ctx, int64_t B);
 int launch_k2_slab(chest_ctx* ctx, hipStream_t st, int32_t B, const chest_frame_desc* descs, int Pmax, uint64_t seed,
-                   uint64_t frame_offset, const chest_injected& inj, const chest_frame_outputs& out, const float* workspace);
+                   uint64_t frame_offset, const chest_injected& inj, const chest_frame_outputs& out, const float* workspace, bool compact);
 int launch_estimate(chest_ctx* ctx, hipStream_t st, int32_t B, const float* rx4d, const float* tx_pilots,
                     int32_t pilot_stride, int32_t slot, int32_t mmse, float snr_db, float* H_est);
 int launch_at_pilots(chest_ctx* ctx, hipStream_t st, int32_t n, const float* rx, const float* tx, int32_t mmse,

@@ -59,6 +59,7 @@ int launch_estimate(chest_ctx* ctx, hipStream_t st, int32_t B, const float* rx4d
     }
     const PatternDev& pd = ctx->patterns[slot].dev;
     if (pd.plan == nullptr) { set_error("pattern slot %d has no interpolation plan", slot); return CHEST_ESTATE; }
+    if (pd.pad != 0) { set_error("pattern slot %d carries a compact plan (chest_patterns_build method 2): only the fused frame pipeline reads those", slot); return CHEST_ESTATE; }
     const size_t lds = (size_t)pd.P * sizeof(float2) + 32 * sizeof(float);
     if (lds > 160 * 1024) { set_error("too many pilots for LDS"); return CHEST_EINVAL; }
     CHEST_LDS_OPT_IN(ctx, LDS_ESTIMATE, estimate_kernel, lds);

@@ -176,7 +176,16 @@ int launch_frames(chest_ctx* ctx, hipStream_t st, int32_t B, const chest_frame_d
     for (const void* q : ptrs)
         if (((uintptr_t)q & 15) != 0) { set_error("chest_frames_run: output/workspace pointers must be 16-byte aligned"); return CHEST_EINVAL; }
     int Pmax = 1;
-    for (const auto& p : ctx->patterns) Pmax = p.dev.P > Pmax ? p.dev.P : Pmax;
+    bool any_compact = false, any_full = false;                  // interpolation-plan formats present in the context
+    for (const auto& p : ctx->patterns) {
+        Pmax = p.dev.P > Pmax ? p.dev.P : Pmax;
+        if (p.dev.plan != nullptr) { if (p.dev.pad != 0) any_compact = true; else any_full = true; }
+    }
+    const bool want_est = out->H_ls != nullptr || out->H_mmse != nullptr || out->metrics != nullptr;
+    if (want_est && any_compact && any_full) {
+        set_error("chest_frames_run: the context holds compact and full interpolation plans; a launch reads one format");
+        return CHEST_ESTATE;
+    }
     const size_t lds1 = ((size_t)KT * fp.T * fp.R * CHEST_NUM_OSC + (size_t)fp.S * fp.R * KTS + (size_t)KT * KT) * sizeof(float2) + 32 * sizeof(float);
     if (lds1 > 160 * 1024) { set_error("taps kernel needs %zu B of LDS (> 160 KiB): too many antennas", lds1); return CHEST_EINVAL; }
     CHEST_LDS_OPT_IN(ctx, LDS_TAPS, taps_kernel, lds1);
@@ -192,7 +201,7 @@ int launch_frames(chest_ctx* ctx, hipStream_t st, int32_t B, const chest_frame_d
                        frame_offset, inj_v.u_angle, inj_v.u_phase, inj_v.inj_paths, (float*)workspace, ctx->d_status, out->frame_status);
     prof_close(ctx, st, sp1);
     const int sp2 = prof_open(ctx, st, CHEST_K_FRAME);
-    const int rc = launch_k2_slab(ctx, st, B, descs, Pmax, seed, frame_offset, inj_v, *out, (const float*)workspace);
+    const int rc = launch_k2_slab(ctx, st, B, descs, Pmax, seed, frame_offset, inj_v, *out, (const float*)workspace, any_compact);
     if (rc != CHEST_OK) return rc;
     prof_close(ctx, st, sp2);
     CHEST_HIP(hipGetLastError());

@@ -115,7 +115,8 @@ __host__ __device__ inline int slab_elems(int T, int RG, int nsc, int SS) {
 // exp(-2 pi j delay/N) (needs an even number of used bins below DC: no pair straddles it; the launcher checks), and both
 // barriers of a unit sit back to back behind the long compute stretch.  0 = run-time values: full twiddle registers,
 // rows written to the slab as they are produced.
-template <int NT, int TT, int RR, int RGT, int SS, bool INJ>
+// CP: the patterns carry compact plans (triangle records + per-element triangle ids, chest_device.h: plan_rec).
+template <int NT, int TT, int RR, int RGT, int SS, bool INJ, bool CP>
 __device__ __forceinline__ void slab_body(const SlabArgs& A) {
     const FrameParams& fp = *A.fp;
     const PatternDev& pat = *A.pat;
@@ -433,10 +434,21 @@ __device__ __forceinline__ void slab_body(const SlabArgs& A) {
     const int seg_l = 0, seg_m = slab_seg(SSN * RG * T, nsc);
     float m_ls = 0.f, m_mm = 0.f;
     PlanRec cn[SSN][2];                                                          // plan records, one unit ahead
+    // compact plans: a record is found through the element's triangle id, so the ids run TWO units ahead of their use and the
+    // records one unit ahead; cn then holds the raw record words, decoded where they are used (plan_rec)
+    const gptr_u16 triof = (gptr_u16)((const CHEST_GLOBAL unsigned char*)pat.plan + (CP ? pat.pad : 0));
+    uint32_t idn[SSN][2];
 #pragma unroll
     for (int ss = 0; ss < SSN; ++ss) {
         const int sy = ss < S ? ss : S - 1;
-        cn[ss][0] = ld_plan(plan, sy * nsc + kc0); cn[ss][1] = ld_plan(plan, sy * nsc + kc1);
+        if constexpr (CP) {
+            cn[ss][0] = ld_plan(plan, triof[sy * nsc + kc0]); cn[ss][1] = ld_plan(plan, triof[sy * nsc + kc1]);
+            const int s2 = SSN + ss < S ? SSN + ss : S - 1;
+            idn[ss][0] = triof[s2 * nsc + kc0]; idn[ss][1] = triof[s2 * nsc + kc1];
+        } else {
+            cn[ss][0] = ld_plan(plan, sy * nsc + kc0); cn[ss][1] = ld_plan(plan, sy * nsc + kc1);
+            idn[ss][0] = idn[ss][1] = 0;
+        }
     }
     first_unit = true;
     // STAGED: a unit's estimates are gathered into registers one unit AHEAD, between the "slab complete" barrier of the unit
@@ -445,13 +457,15 @@ __device__ __forceinline__ void slab_body(const SlabArgs& A) {
     // wave's stores).
     constexpr int EVR = STAGED ? RGT : 1;
     float2 ev[SSN][EVR][2];
-    auto gather = [&](const PlanRec (&c)[SSN][2], int r0, float2 (&e)[SSN][EVR][2]) {
+    auto gather = [&](const PlanRec (&c)[SSN][2], int s0, int r0, float2 (&e)[SSN][EVR][2]) {   // c: records of symbols s0, s0 + 1, ...
 #pragma unroll
-        for (int ss = 0; ss < SSN; ++ss)
+        for (int ss = 0; ss < SSN; ++ss) {
+            const PlanRec c0 = plan_rec<CP>(c[ss][0], s0 + ss, kc0), c1 = plan_rec<CP>(c[ss][1], s0 + ss, kc1);
 #pragma unroll
-            for (int rr = 0; rr < EVR; ++rr) { e[ss][rr][0] = interp(c[ss][0], hp, R, r0 + rr); e[ss][rr][1] = interp(c[ss][1], hp, R, r0 + rr); }
+            for (int rr = 0; rr < EVR; ++rr) { e[ss][rr][0] = interp(c0, hp, R, r0 + rr); e[ss][rr][1] = interp(c1, hp, R, r0 + rr); }
+        }
     };
-    if constexpr (STAGED) gather(cn, 0, ev);
+    if constexpr (STAGED) gather(cn, 0, 0, ev);
     STAMP_ADD(6);                                                                // pilot outputs + alpha
     for (int sb = 0; sb < S; sb += SSN) {
         const int ns = SSN == 1 ? 1 : min(SSN, S - sb);
@@ -460,7 +474,13 @@ __device__ __forceinline__ void slab_body(const SlabArgs& A) {
         for (int ss = 0; ss < SSN; ++ss) {
             cc[ss][0] = cn[ss][0]; cc[ss][1] = cn[ss][1];
             const int sn = sb + SSN + ss;
-            if (sn < S) { cn[ss][0] = ld_plan(plan, sn * nsc + kc0); cn[ss][1] = ld_plan(plan, sn * nsc + kc1); }
+            if (sn < S) {
+                if constexpr (CP) {
+                    cn[ss][0] = ld_plan(plan, idn[ss][0]); cn[ss][1] = ld_plan(plan, idn[ss][1]);
+                    const int s2 = sn + SSN;
+                    if (s2 < S) { idn[ss][0] = triof[s2 * nsc + kc0]; idn[ss][1] = triof[s2 * nsc + kc1]; }
+                } else { cn[ss][0] = ld_plan(plan, sn * nsc + kc0); cn[ss][1] = ld_plan(plan, sn * nsc + kc1); }
+            }
         }
         for (int rg = 0; rg < ngroups; ++rg) {
             const int r0 = rg * RG;
@@ -479,7 +499,7 @@ __device__ __forceinline__ void slab_body(const SlabArgs& A) {
                         const float al = A.alpha[r];
                         float2 e0, e1;
                         if constexpr (STAGED) { e0 = ev[ss][rr][0]; e1 = ev[ss][rr][1]; }
-                        else { e0 = interp(cc[ss][0], hp, R, r); e1 = interp(cc[ss][1], hp, R, r); }
+                        else { e0 = interp(plan_rec<CP>(cc[ss][0], sb + ss, kc0), hp, R, r); e1 = interp(plan_rec<CP>(cc[ss][1], sb + ss, kc1), hp, R, r); }
                         const float2* __restrict__ coef = A.csum_g + (size_t)(sb + ss) * KTS * R + r;      // tap d at stride R
                         float2 hb0 = make_float2(0.f, 0.f), hb1 = make_float2(0.f, 0.f);
 #pragma unroll
@@ -502,7 +522,7 @@ __device__ __forceinline__ void slab_body(const SlabArgs& A) {
                 }
             }
             if (Lb == nullptr && Mb == nullptr) {                                // metrics only: nothing to stream (uniform)
-                if constexpr (STAGED) { if (more) { if (rg + 1 < ngroups) gather(cc, r0 + RG, ev); else gather(cn, 0, ev); } }
+                if constexpr (STAGED) { if (more) { if (rg + 1 < ngroups) gather(cc, sb, r0 + RG, ev); else gather(cn, sb + SSN, 0, ev); } }
                 continue;
             }
             STAMP_ADD(7);                                                        // E compute (metrics)
@@ -518,7 +538,7 @@ __device__ __forceinline__ void slab_body(const SlabArgs& A) {
                         const float al = A.alpha[r];
                         float2 e0, e1;
                         if constexpr (STAGED) { e0 = ev[ss][rr][0]; e1 = ev[ss][rr][1]; }
-                        else { e0 = interp(cc[ss][0], hp, R, r); e1 = interp(cc[ss][1], hp, R, r); }
+                        else { e0 = interp(plan_rec<CP>(cc[ss][0], sb + ss, kc0), hp, R, r); e1 = interp(plan_rec<CP>(cc[ss][1], sb + ss, kc1), hp, R, r); }
                         const float2 f0 = make_float2(al * e0.x, al * e0.y), f1 = make_float2(al * e1.x, al * e1.y);
                         for (int t = 0; t < T; ++t) {
                             const int row = ((ss * RG + rr) * T + t) * nsc;
@@ -532,7 +552,7 @@ __device__ __forceinline__ void slab_body(const SlabArgs& A) {
             __syncthreads();
             STAMP_ADD(10);                                                       // E barrier A
             if constexpr (STAGED) {                                              // the next unit's estimates, ahead of this unit's stores
-                if (more) { if (rg + 1 < ngroups) gather(cc, r0 + RG, ev); else gather(cn, 0, ev); }
+                if (more) { if (rg + 1 < ngroups) gather(cc, sb, r0 + RG, ev); else gather(cn, sb + SSN, 0, ev); }
             }
             if (storer) {
                 int ph = wave;
@@ -565,7 +585,7 @@ __device__ __forceinline__ void slab_body(const SlabArgs& A) {
 }
 
 // MAXTHR: largest workgroup this instantiation is launched with (320 = 5 waves covers nsc <= 640, the 1024-FFT grids).
-template <int MAXTHR, int MINW, int TT, int RR, int RGT, int SS, bool INJ>
+template <int MAXTHR, int MINW, int TT, int RR, int RGT, int SS, bool INJ, bool CP>
 __global__ void __launch_bounds__(MAXTHR, MINW)
 frame_slab_kernel(const FrameParams* __restrict__ fpp, const chest_frame_desc* __restrict__ descs,
                   const PatternDev* __restrict__ patterns, int Pmax, uint64_t seed, uint64_t frame_offset,
@@ -594,11 +614,26 @@ frame_slab_kernel(const FrameParams* __restrict__ fpp, const chest_frame_desc* _
         return;
     }
     const bool want_est = out.H_ls != nullptr || out.H_mmse != nullptr || out.metrics != nullptr;
-    if (want_est && pat.plan == nullptr) {
+    if (want_est && (pat.plan == nullptr || (pat.pad != 0) != CP)) {       // no plan, or not in the format this launch reads
         if (tid == 0) { atomicExch(status, 2); if (out.frame_status) out.frame_status[b] = 2; }
         return;
     }
     const int P = pat.P;
+
+    // Compact plans belong to ONE frame and come from HBM.  A read that misses the caches while the chip is saturated with
+    // this kernel's stores waits microseconds, and the estimate phase would meet one such wait per unit (2.94 ms per 10 000
+    // frames, against 2.0 ms when the tables are cached).  The tables are small enough -- 44 KB at 14 x 599 -- to be pulled in
+    // whole right here, one dword per 128-B line, one or two loads per thread, while the mask below is written: 2.47 ms.
+    uint32_t touch0 = 0, touch1 = 0;
+    if constexpr (CP) {
+        if (want_est) {
+            const CHEST_GLOBAL uint32_t* pw = (const CHEST_GLOBAL uint32_t*)pat.plan;
+            const int nlines = (pat.pad + 2 * G + 127) >> 7;     // triangle records | triangle id of every element
+            touch0 = pw[min(tid, nlines - 1) * 32];
+            touch1 = pw[min(tid + (int)blockDim.x, nlines - 1) * 32];
+            for (int i = tid + 2 * (int)blockDim.x; i < nlines; i += blockDim.x) touch1 += pw[i * 32];
+        }
+    }
 
     // ---- pilot mask: 16 resource elements per thread and one 16-B store, after peeling the row to 16-B alignment
     //      (G is rarely a multiple of 16, so most rows start misaligned) ---------------------------------------------
@@ -635,6 +670,7 @@ frame_slab_kernel(const FrameParams* __restrict__ fpp, const chest_frame_desc* _
         if (tid < G - tail0) mrow[tail0 + tid] = gslot[tail0 + tid] < P ? 1.f : 0.f;
     }
 
+    if constexpr (CP) asm volatile("" :: "v"(touch0), "v"(touch1));          // the touches have landed (nothing else uses their values)
     SlabArgs A;
     A.fp = &fp; A.pat = &pat; A.prof = &fp.prof[fd.channel_type]; A.rec = rec;
     A.c_g = (const float2*)(rec + ST_SCAL);
@@ -648,9 +684,9 @@ frame_slab_kernel(const FrameParams* __restrict__ fpp, const chest_frame_desc* _
     A.key = RngKey{(uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)frame, (uint32_t)(frame >> 32)};
     A.b = b; A.RG = RG;
     switch (A.prof->ntaps) {                                     // workgroup-uniform dispatch on the profile
-        case 5: slab_body<5, TT, RR, RGT, SS, INJ>(A); break;             // EPA at 15.36 MHz
-        case 8: slab_body<8, TT, RR, RGT, SS, INJ>(A); break;             // EVA
-        default: slab_body<KT, TT, RR, RGT, SS, INJ>(A); break;           // ETU / anything else (taps padded with zeros)
+        case 5: slab_body<5, TT, RR, RGT, SS, INJ, CP>(A); break;         // EPA at 15.36 MHz
+        case 8: slab_body<8, TT, RR, RGT, SS, INJ, CP>(A); break;         // EVA
+        default: slab_body<KT, TT, RR, RGT, SS, INJ, CP>(A); break;       // ETU / anything else (taps padded with zeros)
     }
 #ifdef CHEST_STAMPS
     if (g_stamp_buf != nullptr && (tid & 63) == 0) {
@@ -686,18 +722,18 @@ static int choose_rx_group(const chest_ctx* ctx, int Pmax) {
     return best2 ? best2 : best1;
 }
 
-template <int MAXTHR, int MINW, int TT, int RR, int RGT, int SS, bool INJ>
+template <int MAXTHR, int MINW, int TT, int RR, int RGT, int SS, bool INJ, bool CP = false>
 static int launch_one(chest_ctx* ctx, int which, hipStream_t st, dim3 grid, dim3 block, size_t lds, const chest_frame_desc* descs, int Pmax,
                       uint64_t seed, uint64_t frame_offset, const chest_injected& inj, const chest_frame_outputs& out,
                       const float* workspace, int RG) {
-    CHEST_LDS_OPT_IN(ctx, which, (frame_slab_kernel<MAXTHR, MINW, TT, RR, RGT, SS, INJ>), lds);
-    hipLaunchKernelGGL((frame_slab_kernel<MAXTHR, MINW, TT, RR, RGT, SS, INJ>), grid, block, lds, st, ctx->d_fp, descs, ctx->d_patterns, Pmax,
+    CHEST_LDS_OPT_IN(ctx, which, (frame_slab_kernel<MAXTHR, MINW, TT, RR, RGT, SS, INJ, CP>), lds);
+    hipLaunchKernelGGL((frame_slab_kernel<MAXTHR, MINW, TT, RR, RGT, SS, INJ, CP>), grid, block, lds, st, ctx->d_fp, descs, ctx->d_patterns, Pmax,
                        seed, frame_offset, inj, out, workspace, RG, ctx->d_status);
     return CHEST_OK;
 }
 
 int launch_k2_slab(chest_ctx* ctx, hipStream_t st, int32_t B, const chest_frame_desc* descs, int Pmax, uint64_t seed,
-                   uint64_t frame_offset, const chest_injected& inj, const chest_frame_outputs& out, const float* workspace) {
+                   uint64_t frame_offset, const chest_injected& inj, const chest_frame_outputs& out, const float* workspace, bool compact) {
     const FrameParams& fp = ctx->fp;
     const int npair = (fp.nsc + 1) / 2, nwave = (npair + 63) / 64;
     if (nwave > 16) { set_error("frame kernel handles at most 2047 used subcarriers (got %d)", fp.nsc); return CHEST_EINVAL; }
@@ -715,6 +751,17 @@ int launch_k2_slab(chest_ctx* ctx, hipStream_t st, int32_t B, const chest_frame_
     if (lds > 160 * 1024) { set_error("frame kernel needs %zu B of LDS (> 160 KiB): too many antennas, subcarriers or pilots", lds); return CHEST_EINVAL; }
     const dim3 grid((unsigned)B), block((unsigned)nwave * 64);
 #define CHEST_SLAB_ARGS st, grid, block, lds, descs, Pmax, seed, frame_offset, inj, out, workspace, RG
+    if (compact) {
+        // compact plans (chest_patterns_build method 2; every frame of the launch must use one -- the kernel flags a frame whose
+        // pattern is in the other format): the device-RNG instantiations of the 1024-FFT grids and the generic one
+        if (nwave > 5) { set_error("compact interpolation plans are read by the frame kernels of grids up to 640 used subcarriers (got %d)", fp.nsc); return CHEST_EINVAL; }
+        if (!injected && !(fp.half & 1)) {
+            if (T == 2 && R == 2 && RG == 2) return launch_one<320, 5, 2, 2, 2, 1, false, true>(ctx, LDS_FRAME_CP, CHEST_SLAB_ARGS);
+            if (T == 4 && R == 4 && RG == 1) return launch_one<320, 4, 4, 4, 1, 1, false, true>(ctx, LDS_FRAME_44_CP, CHEST_SLAB_ARGS);
+            if (siso) return launch_one<320, 5, 1, 1, 1, SS_SISO, false, true>(ctx, LDS_FRAME_11_CP, CHEST_SLAB_ARGS);
+        }
+        return launch_one<320, 4, 0, 0, 0, 1, true, true>(ctx, LDS_FRAME_GEN_CP, CHEST_SLAB_ARGS);
+    }
     if (nwave <= 5) {                      // the 1024-FFT grids (nsc <= 640): specialised antenna counts on the device-RNG path
         if (!injected) {
             if (fp.half & 1) return launch_one<320, 4, 0, 0, 0, 1, true>(ctx, LDS_FRAME_GEN, CHEST_SLAB_ARGS);   // a pair straddles DC

@@ -394,8 +394,8 @@ int chest_mmse_full_apply(chest_ctx* ctx, void* stream, int32_t B, const float* 
     }
     if (B == 0) return CHEST_OK;
     if (slot < 0 || slot >= (int)ctx->patterns.size() || ctx->patterns[slot].dev.slot == nullptr ||
-        ctx->patterns[slot].dev.plan == nullptr) {
-        set_error("pattern slot %d is not set or has no plan", slot);
+        ctx->patterns[slot].dev.plan == nullptr || ctx->patterns[slot].dev.pad != 0) {
+        set_error("pattern slot %d is not set, has no plan or carries a compact plan", slot);
         return CHEST_ESTATE;
     }
     CHEST_GUARD(ctx);
@@ -430,8 +430,8 @@ int chest_mmse_full_apply_pilots(chest_ctx* ctx, void* stream, int32_t B, const 
     }
     if (B == 0) return CHEST_OK;
     if (slot < 0 || slot >= (int)ctx->patterns.size() || ctx->patterns[slot].dev.slot == nullptr ||
-        ctx->patterns[slot].dev.plan == nullptr) {
-        set_error("pattern slot %d is not set or has no plan", slot);
+        ctx->patterns[slot].dev.plan == nullptr || ctx->patterns[slot].dev.pad != 0) {
+        set_error("pattern slot %d is not set, has no plan or carries a compact plan", slot);
         return CHEST_ESTATE;
     }
     CHEST_GUARD(ctx);

@@ -41,7 +41,7 @@ constexpr int PB_MAX_ROWS = CHEST_MAX_SYMBOLS;
 struct PatBuildArgs {
     PatternDev* table;            // device pattern table; entries first_slot + j are written by the kernel
     unsigned char* pool;          // count blocks of `stride` bytes: slot u16[G] | pilot_idx i32[Pcap] | plan PlanRec[G]
-    size_t stride, o_pil, o_plan;
+    size_t stride, o_pil, o_plan, o_tri;   // o_tri: compact plans only (method 2): u16 triangle id per element behind the record table
     const int32_t* num_pilots;    // [count]
     const int32_t* given_idx;     // [count][idx_stride] sorted flat indices, or nullptr: draw them
     const uint64_t* pattern_ids;  // [count]
@@ -205,7 +205,8 @@ pattern_build_kernel(const PatBuildArgs A) {
     PlanRec* __restrict__ plan = (PlanRec*)(base + A.o_plan);
     if (tid == 0) {
         PatternDev pd;
-        pd.slot = slotp; pd.plan = A.method >= 0 ? (const void*)plan : nullptr; pd.pilot_idx = pil; pd.P = P; pd.pad = 0;
+        pd.slot = slotp; pd.plan = A.method >= 0 ? (const void*)plan : nullptr; pd.pilot_idx = pil; pd.P = P;
+        pd.pad = A.method == 2 ? (int32_t)(A.o_tri - A.o_plan) : 0;       // compact plan: bytes from the triangle records to the per-element ids
         A.table[A.first_slot + j] = pd;
         if (A.nsimp_out) A.nsimp_out[j] = 0;
     }
@@ -673,6 +674,25 @@ pattern_build_kernel(const PatBuildArgs A) {
         if (tid == 0 && A.nsimp_out) A.nsimp_out[j] = ntri;
     }
 
+    // compact plan (method 2): one 16-B record per triangle -- the three pilot ordinals, the three vertex positions
+    // (symbol << 11 | subcarrier) and 1 / (twice the area) -- and one u16 triangle id per resource element; the frame kernel
+    // evaluates the two edge functions itself (chest_device.h: plan_rec).  Record 2 Pcap - 1 (never a triangle: at most
+    // 2 P - 5 exist) stands for "outside the convex hull".
+    const bool compact = A.method == 2;
+    uint16_t* __restrict__ triof = (uint16_t*)(base + A.o_tri);
+    const uint32_t t_outside = (uint32_t)(2 * A.Pcap - 1);
+    if (compact) {
+        uint4* __restrict__ tab = (uint4*)plan;
+        for (int t = tid; t < ntri; t += PB_THREADS) {
+            const TriU T0 = ld_tri(TR, (uint32_t)t);
+            const uint32_t a = pts[T0.v[0]], b = pts[T0.v[1]], c = pts[T0.v[2]];
+            const uint32_t pa = ((uint32_t)px_of(a) << 11) | (uint32_t)py_of(a), pb = ((uint32_t)px_of(b) << 11) | (uint32_t)py_of(b),
+                           pc = ((uint32_t)px_of(c) << 11) | (uint32_t)py_of(c);
+            tab[t] = make_uint4(T0.v[0] | (T0.v[1] << 16), T0.v[2] | (pa << 16), pb | (pc << 16), __float_as_uint(1.0f / (float)orient2(a, b, c)));
+        }
+        if (tid == 0) tab[t_outside] = make_uint4(0u, 0xFFFF0000u, 0u, 0u);
+    }
+
     // ================= 5. plan: walk to the containing triangle =====================================================
     // Every lane owns a run of consecutive elements and runs ONE loop in which an iteration either crosses into the
     // neighbouring triangle or emits the current element and moves one column on (lanes do not wait for each other per
@@ -706,6 +726,7 @@ pattern_build_kernel(const PatBuildArgs A) {
         int t = g < g_hi ? near_tri(s, k) : 0;
         uint32_t i0 = 0, i1 = 0, i2 = 0;
         int o0 = 0, o1 = 0, o2 = 0, d0 = 0, d1 = 0, d2 = 0;
+        uint32_t pend_id = 0;                                     // compact plan: the even element's id waits for its odd neighbour
         bool fresh = true;                                        // triangle t not loaded yet
         int since = 0;                                            // crossings since the last emitted element
         while (g < g_hi) {
@@ -726,10 +747,14 @@ pattern_build_kernel(const PatBuildArgs A) {
 #endif
             if (cross && nx != TNONE && since <= ntri + 8) { t = (int)nx; fresh = true; ++since; continue; }
             PlanRec rec{0.f, 0.f, 0u, 0u};                        // leaving through a hull edge: outside the convex hull
+            uint32_t t_hit = t_outside;
             if (!cross) {
-                const float den = (float)(o0 + o1 + o2);
-                rec.w0 = (float)o0 / den; rec.w1 = (float)o1 / den;
-                rec.i01 = i0 | (i1 << 16); rec.i2v = i2 | (1u << 16);
+                t_hit = (uint32_t)t;
+                if (!compact) {                                   // (a compact plan leaves the weights to its reader)
+                    const float den = (float)(o0 + o1 + o2);
+                    rec.w0 = (float)o0 / den; rec.w1 = (float)o1 / den;
+                    rec.i01 = i0 | (i1 << 16); rec.i2v = i2 | (1u << 16);
+                }
             } else if (nx != TNONE) {
                 // not reached on a Delaunay triangulation (the visibility walk is acyclic); exhaustive scan as a safety net
                 const uint32_t q = ((uint32_t)s << 16) | (uint32_t)k;
@@ -740,15 +765,16 @@ pattern_build_kernel(const PatBuildArgs A) {
                         const float den = (float)(p0 + p1 + p2);
                         rec.w0 = (float)p0 / den; rec.w1 = (float)p1 / den;
                         rec.i01 = j0 | (j1 << 16); rec.i2v = j2 | (1u << 16);
+                        t_hit = (uint32_t)u;
                         break;
                     }
                 }
             }
-#ifdef CHEST_EXP_NOPLAN
-            if (rec.w0 == 123.f) plan[g] = rec;
-#else
-            plan[g] = rec;
-#endif
+            if (!compact) plan[g] = rec;
+            else if (g & 1) {                                     // ids leave in pairs (4-B stores) where the run allows
+                if (g > g_lo) *(uint32_t*)&triof[g - 1] = pend_id | (t_hit << 16); else triof[g] = (uint16_t)t_hit;
+            } else if (g + 1 < g_hi) pend_id = t_hit;
+            else triof[g] = (uint16_t)t_hit;
             ++g; since = 0;
             if (++k == nsc) {                                     // next row: far from here, start again from the layout guess
                 k = 0; ++s;
@@ -757,7 +783,7 @@ pattern_build_kernel(const PatBuildArgs A) {
             } else { o0 += d0; o1 += d1; o2 += d2; }
         }
     } else {
-        for (int g = g_lo; g < g_hi; ++g) plan[g] = PlanRec{0.f, 0.f, 0u, 0u};
+        for (int g = g_lo; g < g_hi; ++g) { if (compact) triof[g] = (uint16_t)t_outside; else plan[g] = PlanRec{0.f, 0.f, 0u, 0u}; }
     }
     PSTAMP(6);                                                   // plan walk
 #ifdef CHEST_STAMPS
@@ -790,7 +816,8 @@ extern "C" int chest_patterns_build(chest_ctx* ctx, void* stream, int32_t first_
         return CHEST_EINVAL;
     }
     if (count == 0) return CHEST_OK;
-    if (method < -1 || method > 1) { set_error("chest_patterns_build: method must be -1 (no plan), 0 ('linear') or 1 ('nearest')"); return CHEST_EINVAL; }
+    if (method < -1 || method > 2) { set_error("chest_patterns_build: method must be -1 (no plan), 0 ('linear'), 1 ('nearest') or 2 ('linear', compact plan)"); return CHEST_EINVAL; }
+    if (method == 2 && (ctx->fp.S > 32 || ctx->fp.nsc > 2047)) { set_error("chest_patterns_build: compact plans pack positions as 5 + 11 bits"); return CHEST_EINVAL; }
     if (pilot_idx == nullptr && pattern_ids == nullptr) { set_error("chest_patterns_build: give pilot_idx or pattern_ids"); return CHEST_EINVAL; }
     CHEST_GUARD(ctx);
     hipStream_t st = (hipStream_t)stream;
@@ -813,7 +840,7 @@ extern "C" int chest_patterns_build(chest_ctx* ctx, void* stream, int32_t first_
     // pool reuse: the slot range is served by one pool whose blocks are large enough -> build in place (stream ordered)
     PatternPool* pool = nullptr;
     for (auto& pl : ctx->pools)
-        if (pl.first_slot == first_slot && pl.count >= count && pl.Pcap >= Pmax) pool = &pl;
+        if (pl.first_slot == first_slot && pl.count >= count && pl.Pcap >= Pmax && pl.compact == (method == 2)) pool = &pl;
     if (pool == nullptr) {
         CHEST_HIP(hipDeviceSynchronize());
         // release whatever owned these slots before
@@ -832,7 +859,14 @@ extern "C" int chest_patterns_build(chest_ctx* ctx, void* stream, int32_t first_
         pl.first_slot = first_slot; pl.count = count; pl.Pcap = Pmax;
         pl.o_pil = up((size_t)G * 2, 16);
         pl.o_plan = up(pl.o_pil + (size_t)Pmax * 4, 256);
-        pl.stride = up(pl.o_plan + (size_t)G * sizeof(PlanRec), 256);
+        pl.compact = method == 2;
+        if (pl.compact) {                                       // triangle records [2 Pmax] | u16 triangle id per element
+            pl.o_tri = up(pl.o_plan + (size_t)2 * Pmax * sizeof(PlanRec), 256);
+            pl.stride = up(pl.o_tri + (size_t)G * 2, 256);
+        } else {
+            pl.o_tri = 0;
+            pl.stride = up(pl.o_plan + (size_t)G * sizeof(PlanRec), 256);
+        }
         if (hipMalloc((void**)&pl.block, pl.stride * (size_t)count) != hipSuccess) { set_error("chest_patterns_build: out of device memory (%zu B)", pl.stride * (size_t)count); return CHEST_ENOMEM; }
         if (hipMalloc((void**)&pl.d_meta, up((size_t)count * sizeof(int32_t), 8) + (size_t)count * sizeof(uint64_t)) != hipSuccess) { (void)hipFree(pl.block); set_error("out of device memory"); return CHEST_ENOMEM; }
         ctx->pools.push_back(pl);
@@ -858,7 +892,7 @@ extern "C" int chest_patterns_build(chest_ctx* ctx, void* stream, int32_t first_
     CHEST_HIP(hipMemcpyAsync(d_np, num_pilots, (size_t)count * sizeof(int32_t), hipMemcpyHostToDevice, st));
     if (pattern_ids) CHEST_HIP(hipMemcpyAsync(d_ids, pattern_ids, (size_t)count * sizeof(uint64_t), hipMemcpyHostToDevice, st));
     PatBuildArgs a{};
-    a.table = ctx->d_patterns; a.pool = (unsigned char*)pool->block; a.stride = pool->stride; a.o_pil = pool->o_pil; a.o_plan = pool->o_plan;
+    a.table = ctx->d_patterns; a.pool = (unsigned char*)pool->block; a.stride = pool->stride; a.o_pil = pool->o_pil; a.o_plan = pool->o_plan; a.o_tri = pool->o_tri;
     a.num_pilots = d_np; a.given_idx = pilot_idx; a.pattern_ids = d_ids; a.seed = seed; a.idx_stride = idx_stride;
     a.first_slot = first_slot; a.S = ctx->fp.S; a.nsc = ctx->fp.nsc; a.method = method; a.Pcap = pool->Pcap;
     a.simp_out = simplices_out; a.nbr_out = simplices_out ? neighbors_out : nullptr; a.nsimp_out = num_simplices_out; a.status = ctx->d_status;
@@ -876,6 +910,7 @@ extern "C" int chest_patterns_build(chest_ctx* ctx, void* stream, int32_t first_
         ph.block = nullptr;                                      // owned by the pool
         ph.dev.slot = (const uint16_t*)base;
         ph.dev.plan = method >= 0 ? (const void*)(base + pool->o_plan) : nullptr;
+        ph.dev.pad = method == 2 ? (int32_t)(pool->o_tri - pool->o_plan) : 0;
         ph.dev.pilot_idx = (const int32_t*)(base + pool->o_pil);
         ph.dev.P = num_pilots[i];
     }

@@ -112,6 +112,12 @@ class ChannelEstimationDataset:
         import torch
         geom = _geometry_from_config(self.config)
         eng = _engine.get_engine(geom)
+        # A plan that belongs to one frame is read once, from HBM: built in the compact format (triangle ids + triangle records,
+        # less than half the bytes) where the frame kernel reads it.  A context holds one plan format, so these patterns live
+        # in an engine of their own, apart from the one the drop-in estimators share.
+        method = "linear"
+        if max(1, int(pattern_group)) == 1 and eng.compact_plans_supported:
+            eng, method = _engine.get_engine(geom, tag="compact"), "linear_compact"
         S, T, R, nsc, G = geom.num_symbols, geom.num_tx, geom.num_rx, geom.num_sc, geom.grid
         channel_types = list(channel_types or self.channel_config['models'])
         doppler_values = list(doppler_values or self.channel_config['doppler_hz'])
@@ -141,7 +147,7 @@ class ChannelEstimationDataset:
             b1 = min(n, b0 + batch_frames)
             ids, inv = np.unique(pat_id[b0:b1], return_inverse=True)
             first = np.zeros(len(ids), dtype=np.int64); first[inv[::-1]] = np.arange(b1 - b0)[::-1]     # a frame of each pattern
-            slots = eng.build_patterns(0, npil_of_density[pi[b0:b1][first]], seed=seed, pattern_ids=ids, method="linear")
+            slots = eng.build_patterns(0, npil_of_density[pi[b0:b1][first]], seed=seed, pattern_ids=ids, method=method)
             descs = _engine.make_descs(ctype[b0:b1], fd[b0:b1], snr[b0:b1], slots[inv], n=b1 - b0)
             out = eng.run_frames(descs, seed=seed, frame_offset=int(begin + b0), outputs=names)
             for k in names:

@@ -191,12 +191,23 @@ class Engine:
     def num_pilots(self, slot: int) -> int:
         return self._slot_P[int(slot)]
 
-    METHOD_CODES = {None: -1, "none": -1, "linear": 0, "nearest": 1}
+    METHOD_CODES = {None: -1, "none": -1, "linear": 0, "nearest": 1, "linear_compact": 2}
+
+    @property
+    def compact_plans_supported(self) -> bool:
+        """Compact 'linear' plans (one u16 triangle id per element + one 16-B record per triangle, 67 KB instead of 151 KB per
+        14 x 599 pattern) are read by the frame kernels of grids up to 640 used subcarriers; they are what a producer that
+        draws a new pattern per frame should build (``build_patterns(..., method="linear_compact")``): the frame kernel then
+        reads less than half the table bytes from HBM.  Only the fused frame pipeline reads them, and a context holds one plan
+        format at a time."""
+        return (self.geom.num_sc + 1) // 2 <= 320
+
 
     def build_patterns(self, first_slot, num_pilots, pilot_idx=None, seed=0, pattern_ids=None, method="linear",
                        return_simplices=False):
         """Build ``len(num_pilots)`` patterns and their plans ON THE DEVICE in slots ``first_slot ...`` (one launch, one
-        workgroup per pattern: pilot selection, slot table, Delaunay triangulation / nearest search, plan).  Either
+        workgroup per pattern: pilot selection, slot table, Delaunay triangulation / nearest search, plan; ``method`` "linear",
+        "nearest", "linear_compact" (see ``compact_plans_supported``) or None for simulation-only patterns).  Either
         ``pattern_ids`` (uint64 per pattern: the pilots are drawn on the device from (seed, id)) or ``pilot_idx`` (device or
         host int32 [count, stride] rows of sorted flat indices).  Rebuilding the same slot range reuses its storage in
         place, ordered on the current stream.  Returns the slot numbers (and, on request, (simplices, counts) tensors)."""
@@ -768,10 +779,11 @@ class Engine:
 _ENGINES = {}
 
 
-def get_engine(geometry: Geometry, device=None) -> Engine:
-    """Process-wide engine cache keyed by geometry and device."""
+def get_engine(geometry: Geometry, device=None, tag: str = "") -> Engine:
+    """Process-wide engine cache keyed by geometry, device and ``tag`` (a context holds interpolation plans of one format, so
+    the producers of compact per-frame plans keep an engine of their own: tag "compact")."""
     dev = torch.cuda.current_device() if device is None else device
-    key = (geometry, dev)
+    key = (geometry, dev, tag)
     e = _ENGINES.get(key)
     if e is None:
         e = Engine(geometry, dev)

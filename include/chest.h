@@ -160,6 +160,13 @@ int chest_pattern_set_triangulation(chest_ctx* ctx, int32_t slot, const int32_t*
  *              Qhull's wherever the triangulation is unique, an arbitrary valid choice inside co-circular polygons), then
  *              per resource element the containing triangle and its barycentric weights, 0 outside the hull;
  *            1 'nearest': nearest pilot by squared lattice distance, ties to the smaller pilot ordinal;
+ *            2 'linear' as method 0, stored as a COMPACT plan: one u16 triangle id per resource element and one 16-B record per
+ *              triangle (pilot ordinals, vertex positions, 1 / (2 area)); the reader evaluates the two edge functions itself.
+ *              67 KB instead of 151 KB per 14 x 599 pattern, small enough for the frame kernel to pull into the caches at the
+ *              start of a frame -- the format for patterns that are used by ONE frame (the reference draws a new pattern in
+ *              every simulate_transmission, src/channel_simulator.py:390-391).  Read by chest_frames_run on grids of up to 640
+ *              used subcarriers only (not by chest_estimate / chest_mmse_full_apply*; chest_pattern_get_plan expands it); a
+ *              launch reads ONE plan format: chest_frames_run refuses estimates while the context holds both kinds;
  *           -1 no plan (simulation only).
  *   num_pilots, pattern_ids: HOST arrays [count].  simplices_out (optional, DEVICE int32 [count][2*Pmax][3], Pmax =
  *   max num_pilots) / num_simplices_out (DEVICE int32 [count]) / neighbors_out (optional with simplices_out, same shape: the
