@@ -190,6 +190,8 @@ __device__ unsigned long long* g_pat_stamp = nullptr;           // [count][16]: 
 #define PSTAMP(i) do { } while (0)
 #endif
 
+// COMPACT: method 2 (compact 'linear' plan); a template parameter so that the full-plan kernel carries none of its code
+template <bool COMPACT>
 __global__ void __launch_bounds__(PB_THREADS)
 pattern_build_kernel(const PatBuildArgs A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -206,7 +208,7 @@ pattern_build_kernel(const PatBuildArgs A) {
     if (tid == 0) {
         PatternDev pd;
         pd.slot = slotp; pd.plan = A.method >= 0 ? (const void*)plan : nullptr; pd.pilot_idx = pil; pd.P = P;
-        pd.pad = A.method == 2 ? (int32_t)(A.o_tri - A.o_plan) : 0;       // compact plan: bytes from the triangle records to the per-element ids
+        pd.pad = COMPACT ? (int32_t)(A.o_tri - A.o_plan) : 0;       // compact plan: bytes from the triangle records to the per-element ids
         A.table[A.first_slot + j] = pd;
         if (A.nsimp_out) A.nsimp_out[j] = 0;
     }
@@ -678,7 +680,7 @@ pattern_build_kernel(const PatBuildArgs A) {
     // (symbol << 11 | subcarrier) and 1 / (twice the area) -- and one u16 triangle id per resource element; the frame kernel
     // evaluates the two edge functions itself (chest_device.h: plan_rec).  Record 2 Pcap - 1 (never a triangle: at most
     // 2 P - 5 exist) stands for "outside the convex hull".
-    const bool compact = A.method == 2;
+    constexpr bool compact = COMPACT;
     uint16_t* __restrict__ triof = (uint16_t*)(base + A.o_tri);
     const uint32_t t_outside = (uint32_t)(2 * A.Pcap - 1);
     if (compact) {
@@ -726,7 +728,7 @@ pattern_build_kernel(const PatBuildArgs A) {
         int t = g < g_hi ? near_tri(s, k) : 0;
         uint32_t i0 = 0, i1 = 0, i2 = 0;
         int o0 = 0, o1 = 0, o2 = 0, d0 = 0, d1 = 0, d2 = 0;
-        uint32_t pend_id = 0;                                     // compact plan: the even element's id waits for its odd neighbour
+        uint64_t id_lo = 0, id_hi = 0;                            // compact plan: the last eight triangle ids, waiting for their 16-B store
         bool fresh = true;                                        // triangle t not loaded yet
         int since = 0;                                            // crossings since the last emitted element
         while (g < g_hi) {
@@ -771,10 +773,21 @@ pattern_build_kernel(const PatBuildArgs A) {
                 }
             }
             if (!compact) plan[g] = rec;
-            else if (g & 1) {                                     // ids leave in pairs (4-B stores) where the run allows
-                if (g > g_lo) *(uint32_t*)&triof[g - 1] = pend_id | (t_hit << 16); else triof[g] = (uint16_t)t_hit;
-            } else if (g + 1 < g_hi) pend_id = t_hit;
-            else triof[g] = (uint16_t)t_hit;
+            else {
+                // ids leave eight at a time (one aligned 16-B store per group of elements 8 j ... 8 j + 7): they are shifted through a
+                // 128-bit register, newest on top; a group cut by the ends of the run goes out as single u16 stores
+                id_lo = (id_lo >> 16) | (id_hi << 48);
+                id_hi = (id_hi >> 16) | ((uint64_t)t_hit << 48);
+                if ((g & 7) == 7 || g + 1 == g_hi) {
+                    const int n_in = min(g - g_lo + 1, (g & 7) + 1);              // elements of the group that are mine: the newest n_in
+                    if (n_in == 8) *(uint4*)&triof[g - 7] = make_uint4((uint32_t)id_lo, (uint32_t)(id_lo >> 32), (uint32_t)id_hi, (uint32_t)(id_hi >> 32));
+                    else
+                        for (int j = 0; j < n_in; ++j) {                             // element g - j sits in 16-bit slot 7 - j
+                            const int sl = 7 - j;
+                            triof[g - j] = (uint16_t)(sl >= 4 ? (id_hi >> (16 * (sl - 4))) : (id_lo >> (16 * sl)));
+                        }
+                }
+            }
             ++g; since = 0;
             if (++k == nsc) {                                     // next row: far from here, start again from the layout guess
                 k = 0; ++s;
@@ -898,9 +911,14 @@ extern "C" int chest_patterns_build(chest_ctx* ctx, void* stream, int32_t first_
     a.simp_out = simplices_out; a.nbr_out = simplices_out ? neighbors_out : nullptr; a.nsimp_out = num_simplices_out; a.status = ctx->d_status;
     if (simplices_out && pool->Pcap != Pmax) { set_error("chest_patterns_build: simplices_out needs a fresh slot range (row stride is 2*Pmax*3)"); return CHEST_EINVAL; }
     const size_t lds_run = pattern_build_lds_bytes(G, pool->Pcap) + (size_t)ctx->tune_pattern_extra_lds;
-    CHEST_LDS_OPT_IN(ctx, LDS_DELAUNAY, pattern_build_kernel, lds_run);
     const int sp = prof_open(ctx, st, CHEST_K_PLAN);
-    hipLaunchKernelGGL(pattern_build_kernel, dim3((unsigned)count), dim3(PB_THREADS), lds_run, st, a);
+    if (method == 2) {
+        CHEST_LDS_OPT_IN(ctx, LDS_DELAUNAY_CP, pattern_build_kernel<true>, lds_run);
+        hipLaunchKernelGGL(pattern_build_kernel<true>, dim3((unsigned)count), dim3(PB_THREADS), lds_run, st, a);
+    } else {
+        CHEST_LDS_OPT_IN(ctx, LDS_DELAUNAY, pattern_build_kernel<false>, lds_run);
+        hipLaunchKernelGGL(pattern_build_kernel<false>, dim3((unsigned)count), dim3(PB_THREADS), lds_run, st, a);
+    }
     prof_close(ctx, st, sp);
     CHEST_HIP(hipGetLastError());
     // host mirror of the table entries

@@ -20,7 +20,7 @@ def main():
     if len(sys.argv) > 2:                       # occupancy experiment: extra (unused) LDS bytes per workgroup
         eng.tune("pattern_extra_lds", int(sys.argv[2]))
     G = geom.grid
-    for dens, method in ((0.10, "linear"), (0.05, "linear"), (0.01, "linear"), (0.10, "nearest"), (0.10, None)):
+    for dens, method in ((0.10, "linear"), (0.05, "linear"), (0.01, "linear"), (0.10, "nearest"), (0.10, None), (0.10, "linear_compact"), (0.05, "linear_compact")):
         P = int(G * dens)
         ids = np.arange(n, dtype=np.uint64)
         eng.build_patterns(0, [P] * n, seed=1, pattern_ids=ids, method=method)
