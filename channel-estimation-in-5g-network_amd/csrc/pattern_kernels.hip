@@ -388,17 +388,29 @@ pattern_build_kernel(const PatBuildArgs A) {
         // ================= 'nearest' plan ========================================================================
         int g = g_lo;
         int s = g / nsc, k = g - s * nsc;
+        // occupied rows are visited outwards from the element's own row and the search stops once a row is further away than
+        // the best pilot found (rows are 1 apart, pilots of a row ~10): a handful of rows instead of all of them.  Ties go to
+        // the smaller pilot ordinal whatever the visiting order.
+        int qlo = 0;                                             // occupied rows below index qlo lie above row s
+        while (qlo < m && occ[qlo] < s) ++qlo;
         for (; g < g_hi; ++g) {
             int best = 0x7fffffff, bi = 0;
-            for (int q = 0; q < m; ++q) {
+            auto visit = [&](int q) {
                 const int r = occ[q], a = rowstart[r], n = rowstart[r + 1] - a;
                 const int c = count_less(pts + a, n, ((uint32_t)r << 16) | (uint32_t)k);      // first column >= k
                 const int dr = (r - s) * (r - s);
-                if (c > 0) { const int dc = k - py_of(pts[a + c - 1]); const int d2 = dr + dc * dc; if (d2 < best) { best = d2; bi = a + c - 1; } }
-                if (c < n) { const int dc = py_of(pts[a + c]) - k; const int d2 = dr + dc * dc; if (d2 < best) { best = d2; bi = a + c; } }
+                if (c > 0) { const int dc = k - py_of(pts[a + c - 1]); const int d2 = dr + dc * dc; if (d2 < best || (d2 == best && a + c - 1 < bi)) { best = d2; bi = a + c - 1; } }
+                if (c < n) { const int dc = py_of(pts[a + c]) - k; const int d2 = dr + dc * dc; if (d2 < best || (d2 == best && a + c < bi)) { best = d2; bi = a + c; } }
+            };
+            int up = qlo - 1, dn = qlo;                          // next candidates above / at-or-below row s
+            while (up >= 0 || dn < m) {
+                const int du = up >= 0 ? s - occ[up] : 0x7fff, dd = dn < m ? occ[dn] - s : 0x7fff;
+                const int dmin = du < dd ? du : dd;
+                if (dmin * dmin > best) break;                   // every remaining row is further away than the best pilot
+                if (du <= dd) visit(up--); else visit(dn++);
             }
             plan[g] = PlanRec{1.0f, 0.0f, (uint32_t)bi | ((uint32_t)bi << 16), (uint32_t)bi | (1u << 16)};
-            if (++k == nsc) { k = 0; ++s; }
+            if (++k == nsc) { k = 0; ++s; while (qlo < m && occ[qlo] < s) ++qlo; }
         }
         return;
     }
