@@ -465,15 +465,17 @@ pattern_build_kernel(const PatBuildArgs A) {
     // first (left) / last (right) pilot of every occupied row; every boundary edge of the scan carries its owner (triangle,
     // slot), so each pocket triangle is linked to its neighbours in O(1).
     if (tid == 0) {
+        // (one thread's chain of dependent LDS operations is the whole cost here: the two topmost chain points and their
+        // positions stay in registers, a triangle record is read and written whole)
         int nt = nstrip;
-        auto link = [&](uint32_t own, int t, int c) {            // make `own` and slot c of triangle t neighbours
-            if (own == 0xFFFFFFFFu) return;
-            TR[t].h[3 + (c)] = (uint16_t)(own >> 2);
-            TR[own >> 2].h[3 + ((int)(own & 3u))] = (uint16_t)t;
+        auto back_link = [&](uint32_t own, int t) {               // the owner of an edge learns its new neighbour
+            if (own != 0xFFFFFFFFu) TR[own >> 2].h[3 + ((int)(own & 3u))] = (uint16_t)t;
         };
         auto slot_of_edge = [&](int t, uint32_t x, uint32_t y) -> int {     // slot of t whose edge joins x and y
+            const TriU Te = ld_tri(TR, (uint32_t)t);
+#pragma unroll
             for (int d = 0; d < 3; ++d) {
-                const uint32_t e0 = TR[t].h[(d + 1) % 3], e1 = TR[t].h[(d + 2) % 3];
+                const uint32_t e0 = Te.v[(d + 1) % 3], e1 = Te.v[(d + 2) % 3];
                 if ((e0 == x && e1 == y) || (e0 == y && e1 == x)) return d;
             }
             return 0;
@@ -481,44 +483,54 @@ pattern_build_kernel(const PatBuildArgs A) {
         for (int q = 0; q < m; ++q) rung[q] = 0xFFFFFFFFu;
         for (int side = 0; side < 2; ++side) {
             int sp = 0;
+            int top = 0, sec = 0;                                 // stack[sp - 1], stack[sp - 2]
+            uint32_t ptop = 0, psec = 0;                          // and their positions
             for (int q = 0; q < m; ++q) {
                 const int r = occ[q];
                 const int p = side == 0 ? rowstart[r] : rowstart[r + 1] - 1;
+                const uint32_t pp = pts[p];
                 // owner of the chain edge (previous chain point, p): the first / last triangle of strip q - 1
                 uint32_t cur = 0xFFFFFFFFu;
+                bool empty_strip = false;
                 if (q > 0) {
-                    const int nq = toff[q] - toff[q - 1];
+                    const int t0 = toff[q - 1], nq = toff[q] - t0;
                     if (nq > 0) {
-                        const int te = side == 0 ? toff[q - 1] : toff[q - 1] + nq - 1;
-                        cur = ((uint32_t)te << 2) | (uint32_t)slot_of_edge(te, (uint32_t)stack[sp - 1], (uint32_t)p);
-                    } else cur = rung[q - 1];                    // both rows hold one pilot: the edge belongs to both chains
+                        const int te = side == 0 ? t0 : t0 + nq - 1;
+                        cur = ((uint32_t)te << 2) | (uint32_t)slot_of_edge(te, (uint32_t)top, (uint32_t)p);
+                    } else { cur = rung[q - 1]; empty_strip = true; }   // both rows hold one pilot: the edge belongs to both chains
                 }
-                const bool empty_strip = q > 0 && toff[q] - toff[q - 1] <= 0;
                 int cur_q = empty_strip ? q - 1 : -1;            // cur is still the bare chain edge of that (triangle-less) strip
                 while (sp >= 2) {
-                    const int a = stack[sp - 2], b = stack[sp - 1];
-                    const int o = orient2(pts[a], pts[b], pts[p]);
-                    // b lies in a pocket if it is on the inner side of a -> p (left chain: o < 0, right chain: o > 0)
+                    const int o = orient2(psec, ptop, pp);
+                    // the top point lies in a pocket if it is on the inner side of sec -> p (left chain: o < 0, right chain: o > 0)
                     if (!(side == 0 ? o < 0 : o > 0)) break;
-                    // counter-clockwise: (a, p, b) on the left chain, (a, b, p) on the right one
+                    // counter-clockwise: (a, p, b) on the left chain, (a, b, p) on the right one; a = sec, b = top
                     const int t = nt++;
-                    TR[t].h[0] = (uint16_t)a; TR[t].h[1] = (uint16_t)(side == 0 ? p : b); TR[t].h[2] = (uint16_t)(side == 0 ? b : p);
-                    TR[t].h[3] = TR[t].h[4] = TR[t].h[5] = (uint16_t)TNONE;
-                    const int s_ab = side == 0 ? 1 : 2;          // edge (a, b) is opposite p
-                    const int s_bp = 0;                          // edge (b, p) is opposite a
-                    const int s_ap = side == 0 ? 2 : 1;          // edge (a, p) is opposite b
-                    link(eown[sp - 1], t, s_ab);
-                    link(cur, t, s_bp);
+                    const uint32_t own_ab = eown[sp - 1];
+                    const uint32_t n_ab = own_ab != 0xFFFFFFFFu ? own_ab >> 2 : TNONE, n_bp = cur != 0xFFFFFFFFu ? cur >> 2 : TNONE;
+                    // edge (b, p) is opposite a (slot 0); edge (a, b) is opposite p: slot 1 on the left chain, 2 on the right one;
+                    // edge (a, p), opposite b, is the new chain edge: its neighbour comes later
+                    const int s_ab = side == 0 ? 1 : 2, s_ap = side == 0 ? 2 : 1;
+                    st_tri(TR, (uint32_t)t, (uint32_t)sec, (uint32_t)(side == 0 ? p : top), (uint32_t)(side == 0 ? top : p),
+                           n_bp, side == 0 ? n_ab : TNONE, side == 0 ? TNONE : n_ab, 0u);
+                    back_link(own_ab, t);
+                    back_link(cur, t);
                     // a chain edge shared by both chains (strip without triangles): remember who took it on the left pass
-                    if (side == 0 && eq[sp - 1] >= 0) rung[eq[sp - 1]] = ((uint32_t)t << 2) | (uint32_t)s_ab;
-                    if (side == 0 && cur_q >= 0) rung[cur_q] = ((uint32_t)t << 2) | (uint32_t)s_bp;
+                    if (side == 0) {
+                        const int e = eq[sp - 1];
+                        if (e >= 0) rung[e] = ((uint32_t)t << 2) | (uint32_t)s_ab;
+                        if (cur_q >= 0) rung[cur_q] = ((uint32_t)t << 2) | 0u;
+                    }
                     cur_q = -1;
                     cur = ((uint32_t)t << 2) | (uint32_t)s_ap;
                     --sp;
+                    top = sec; ptop = psec;
+                    if (sp >= 2) { sec = stack[sp - 2]; psec = pts[sec]; }
                 }
                 eown[sp] = cur;
                 eq[sp] = cur_q;
                 stack[sp++] = p;
+                sec = top; psec = ptop; top = p; ptop = pp;
             }
         }
         cnt_s[2] = nt;
@@ -738,14 +750,15 @@ pattern_build_kernel(const PatBuildArgs A) {
         int g = g_lo;
         int s = g / nsc, k = g - s * nsc;
         int t = g < g_hi ? near_tri(s, k) : 0;
-        uint32_t i0 = 0, i1 = 0, i2 = 0;
+        uint32_t i0 = 0, i1 = 0, i2 = 0, n0 = TNONE, n1 = TNONE, n2 = TNONE;
         int o0 = 0, o1 = 0, o2 = 0, d0 = 0, d1 = 0, d2 = 0;
         uint64_t id_lo = 0, id_hi = 0;                            // compact plan: the last eight triangle ids, waiting for their 16-B store
         bool fresh = true;                                        // triangle t not loaded yet
         int since = 0;                                            // crossings since the last emitted element
         while (g < g_hi) {
             if (fresh) {
-                i0 = TR[t].h[0]; i1 = TR[t].h[1]; i2 = TR[t].h[2];
+                const TriU Tc = ld_tri(TR, (uint32_t)t);          // vertices and neighbours in one read: a crossing needs no second one
+                i0 = Tc.v[0]; i1 = Tc.v[1]; i2 = Tc.v[2]; n0 = Tc.n[0]; n1 = Tc.n[1]; n2 = Tc.n[2];
                 const uint32_t a = pts[i0], b = pts[i1], c = pts[i2], q = ((uint32_t)s << 16) | (uint32_t)k;
                 o0 = orient2(b, c, q); o1 = orient2(c, a, q); o2 = orient2(a, b, q);
                 d0 = px_of(c) - px_of(b); d1 = px_of(a) - px_of(c); d2 = px_of(b) - px_of(a);   // d(orient(u, v, q)) / d(column of q) = v.x - u.x
@@ -753,9 +766,9 @@ pattern_build_kernel(const PatBuildArgs A) {
             }
             uint32_t nx = TNONE;
             bool cross = false;
-            if (o0 < 0) { nx = TR[t].h[3]; cross = true; }
-            else if (o1 < 0) { nx = TR[t].h[4]; cross = true; }
-            else if (o2 < 0) { nx = TR[t].h[5]; cross = true; }
+            if (o0 < 0) { nx = n0; cross = true; }
+            else if (o1 < 0) { nx = n1; cross = true; }
+            else if (o2 < 0) { nx = n2; cross = true; }
 #ifdef CHEST_STAMPS
             if (cross && nx != TNONE) ++dbg_cross;
 #endif
