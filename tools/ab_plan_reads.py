@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--m", default="10,100,768,2000,10000")
     ap.add_argument("--reps", type=int, default=7)
     ap.add_argument("--blocked", action="store_true")
+    ap.add_argument("--method", default="linear", choices=["linear", "linear_compact"], help="plan format of the patterns")
     ap.add_argument("--outputs", default="tx,rx,H,H_ls,H_mmse,pilot_symbols,pilot_mask")
     args = ap.parse_args()
     import torch
@@ -33,7 +34,7 @@ def main():
     G = geom.grid
     P = int(G * 0.1)
     eng = E.Engine(geom, 0)
-    eng.build_patterns(0, np.full(F, P, np.int32), seed=2024, pattern_ids=np.arange(F, dtype=np.uint64), method="linear")
+    eng.build_patterns(0, np.full(F, P, np.int32), seed=2024, pattern_ids=np.arange(F, dtype=np.uint64), method=args.method)
     out = None
     for M in [int(x) for x in args.m.split(",")]:
         sl = (np.arange(F) % M) if not args.blocked else (np.arange(F) * M // F)
@@ -49,7 +50,7 @@ def main():
             if rep >= 2:
                 ts.append(ms)
         eng.check_status()
-        print(f"M = {M:6d} ({'blocked' if args.blocked else 'cyclic'}): frame kernel {np.median(ts):.3f} ms (min {min(ts):.3f})", flush=True)
+        print(f"{args.method} M = {M:6d} ({'blocked' if args.blocked else 'cyclic'}): frame kernel {np.median(ts):.3f} ms (min {min(ts):.3f})", flush=True)
 
 
 if __name__ == "__main__":
