@@ -254,3 +254,24 @@ def test_utils_host_helpers_follow_the_reference():
     assert r.shape == (4, 3, 2) and np.array_equal(r[..., 0], z.real) and np.array_equal(U.real_to_complex(r), z)
     with pytest.raises(NotImplementedError):
         U.qam_modulation(np.zeros(6, dtype=int), 64)          # rejected before any device work, like the reference (:104)
+
+
+def test_delaunay_cpu_model_of_the_device_triangulator_is_valid():
+    """tools/delaunay_model.py is the CPU model csrc/pattern_kernels.hip follows (row strips merged by edge midpoint, pockets,
+    rounds of independent Lawson flips with exact integer predicates): on random lattice patterns its result passes its own
+    exact Delaunay check, has as many triangles as Qhull's, and the midpoint merge needs fewer flips than merging by column
+    (the property the kernel's start triangulation was chosen for)."""
+    import importlib.util
+    from scipy.spatial import Delaunay
+    spec = importlib.util.spec_from_file_location("delaunay_model", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "delaunay_model.py"))
+    M = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(M)
+    S, nsc = 14, 73
+    for seed, P in ((1, 40), (2, 100), (3, 300), (4, 5)):
+        idx = np.sort(np.random.RandomState(seed).permutation(S * nsc)[:P])
+        px, py = (idx // nsc).astype(np.int64), (idx % nsc).astype(np.int64)
+        tri, nbr = M.initial_triangulation(px, py)
+        rounds, flips = M.flip_rounds(px, py, tri, nbr)
+        assert M.is_delaunay(px, py, tri, nbr)
+        assert len(tri) == len(Delaunay(np.column_stack([px, py])).simplices)
+        assert rounds < 40 and flips < 4 * P
