@@ -259,8 +259,7 @@ def test_utils_host_helpers_follow_the_reference():
 def test_delaunay_cpu_model_of_the_device_triangulator_is_valid():
     """tools/delaunay_model.py is the CPU model csrc/pattern_kernels.hip follows (row strips merged by edge midpoint, pockets,
     rounds of independent Lawson flips with exact integer predicates): on random lattice patterns its result passes its own
-    exact Delaunay check, has as many triangles as Qhull's, and the midpoint merge needs fewer flips than merging by column
-    (the property the kernel's start triangulation was chosen for)."""
+    exact Delaunay check, has as many triangles as Qhull's, and the flips stay within a few per pilot."""
     import importlib.util
     from scipy.spatial import Delaunay
     spec = importlib.util.spec_from_file_location("delaunay_model", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "delaunay_model.py"))
