@@ -235,40 +235,59 @@ def _pmc_traffic(workload, F, group):
     return None, None
 
 
-def run(args):
+class Job:
+    """Process-group context shared by the legs of one bench process."""
+    def __init__(self, args):
+        import torch
+        import torch.distributed as dist
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local = int(os.environ.get("LOCAL_RANK", "0"))
+        self.backend = args.dist_backend
+        if args.gpus != self.world:
+            raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={self.world}")
+        if self.backend == "gloo":
+            self.local = self.local % max(1, torch.cuda.device_count())
+        torch.cuda.set_device(self.local)
+        # collectives run for N > 1, and for N = 1 when --rccl-rehearsal asks for them (a one-rank RCCL communicator: proves the
+        # library loads and the job's collectives accept these tensors before the first multi-GPU run)
+        self.collectives = self.world > 1 or args.rccl_rehearsal
+        if self.collectives:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if self.world == 1:
+                os.environ.setdefault("MASTER_PORT", str(_free_port()))
+            if self.backend == "nccl":
+                dist.init_process_group("nccl", rank=self.rank, world_size=self.world, device_id=torch.device("cuda", self.local))
+            else:
+                dist.init_process_group("gloo", rank=self.rank, world_size=self.world)
+        self.coll_dev = torch.device("cuda", self.local) if self.backend == "nccl" else torch.device("cpu")
+
+    def close(self):
+        import torch.distributed as dist
+        if self.collectives:
+            dist.destroy_process_group()
+
+
+def measure_leg(job, args, workload, group, steps, warmup, frames=None, patterns_resident=False, cpu=False):
+    """One measured leg: `warmup` untimed steps, then `steps` timed steps of `workload` on every rank, barrier + synchronize on
+    both sides, MAX over ranks.  Returns the result record (rank 0) or None (other ranks)."""
     import torch
     import torch.distributed as dist
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.selftest_spawn:
-        return _selftest_spawn(world, rank)
-    if args.gpus != world:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if args.dist_backend == "gloo":
-        local = local % max(1, torch.cuda.device_count())
-    torch.cuda.set_device(local)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.dist_backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
-        else:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-    coll_dev = torch.device("cuda", local) if args.dist_backend == "nccl" else torch.device("cpu")
-
+    world, rank, local, coll_dev = job.world, job.rank, job.local, job.coll_dev
+    use_coll = job.collectives
     E = importlib.import_module(PKG + ".engine")
     SH = importlib.import_module(PKG + ".sharding")
     IP = importlib.import_module(PKG + ".interp_plan")
-    w = WORKLOADS[args.workload]
+    w = WORKLOADS[workload]
     kind = w["kind"]
     T, R, N, cp, U = w["T"], w["R"], w["N"], w["cp"], w["U"]
-    F = args.frames or w["frames"]
+    F = frames or w["frames"]
     geom = E.Geometry(fft_size=N, cp_length=cp, num_symbols=14, useful_subcarriers=U, num_tx=T, num_rx=R)
     eng = E.Engine(geom, local)
     S, nsc, G = geom.num_symbols, geom.num_sc, geom.grid
     seed = 42 if kind == "dataset" else 2024
-    total_steps = args.warmup + args.steps
-    group = max(1, args.pattern_group)
+    total_steps = warmup + steps
+    group = max(1, group)
     workers = args.plan_workers or min(16, os.cpu_count() or 1)
 
     # ---- inputs resident in HBM before the timed region: patterns, plans (descriptors too, except for the dataset) -------
@@ -303,7 +322,7 @@ def run(args):
         npat = 1 if kind == "fullcov" else (F + group - 1) // group
         # one pattern per frame: the pattern belongs to the frame (simulate_transmission draws it), so it is built inside
         # the timed step from (seed, global frame index) unless --patterns-resident asks for the plans to be pre-built
-        per_step_patterns = device_patterns and group == 1 and kind == "frames" and not args.patterns_resident
+        per_step_patterns = device_patterns and group == 1 and kind == "frames" and not patterns_resident
         # a pattern (and plan) per frame is read once, from HBM: the compact plan format; shared patterns stay in L2: the full one
         pf_method = "linear_compact" if (group == 1 and kind == "frames" and eng.compact_plans_supported) else "linear"
         if device_patterns:
@@ -383,11 +402,11 @@ def run(args):
             W.copy_(eng.mmse_full_prepare(cov, w["snr"]))
             torch.cuda.synchronize()
         t_prep = time.perf_counter() - t_prep
-        if world > 1:
+        if use_coll:
             if args.dist_backend == "nccl":
-                SH.broadcast_from_root(W, 0)
+                SH.broadcast_from_root(W, 0, force_collective=True)
             else:
-                Wc = W.cpu(); SH.broadcast_from_root(Wc, 0); W.copy_(Wc)
+                Wc = W.cpu(); SH.broadcast_from_root(Wc, 0, force_collective=True); W.copy_(Wc)
         scr = eng.mmse_full_scratch(slots[0], F * R)
         out["H_mmse"] = eng.empty_c64(F, S, R, T, nsc)
         extra.update(prepare_s=round(t_prep, 3))
@@ -414,20 +433,20 @@ def run(args):
     else:
         mse_out = eng.run_frames(d_first, seed=seed, frame_offset=rank * F, outputs=("metrics",))["metrics"].double()
         summ = torch.stack([mse_out[:, 0].sum(), mse_out[:, 1].sum(), mse_out[:, 2].sum(), mse_out[:, 6].sum()])
-    for i in range(args.warmup):
+    for i in range(warmup):
         step(i)
-    if world > 1:
+    if use_coll:
         dist.barrier()
     torch.cuda.synchronize()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    eng.profile_begin(args.steps)            # library-side HIP events around each kernel, on the launch stream
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    eng.profile_begin(steps)                 # library-side HIP events around each kernel, on the launch stream
     t0 = time.perf_counter()
-    for i in range(args.steps):
+    for i in range(steps):
         ev[i][0].record()
-        step(args.warmup + i)
+        step(warmup + i)
         ev[i][1].record()
     # the job's single collective: per-rank metric sums gathered to rank 0 (RCCL over xGMI)
-    if world > 1:
+    if use_coll:
         summ_c = summ.to(coll_dev)
         gathered = [torch.zeros_like(summ_c) for _ in range(world)] if rank == 0 else None
         dist.gather(summ_c, gathered, dst=0)
@@ -437,7 +456,7 @@ def run(args):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     eng.check_status()
-    if world > 1:
+    if use_coll:
         tmax = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
@@ -445,15 +464,17 @@ def run(args):
     kern = eng.profile_read_all()                                        # {kernel name: average ms per launch}
     eng.profile_begin(0)
 
+    res = None
     if rank == 0:
         taps_ms, kern_ms = kern.get("taps_kernel", 0.0), kern.get("frame_kernel", 0.0)
-        cfgd = {"workload": args.workload, "frames_per_step_per_gpu": F, "mimo": f"{T}x{R}", "fft_size": N, "pilots": P,
+        cfgd = {"workload": workload, "frames_per_step_per_gpu": F, "mimo": f"{T}x{R}", "fft_size": N, "pilots": P,
                 "pattern_group": group, "patterns": npatterns,
                 "pattern_source": ("device: Philox pilot selection + Delaunay + plan in one launch" + (", rebuilt inside every timed step" if per_step_patterns else ""))
                 if device_patterns else "host: legacy shuffle + Qhull",
                 "host_plan_build_s": round(t_plan, 2) if not device_patterns else 0.0, "plan_build_s": round(t_plan, 3),
                 "host_plan_workers": workers, "output_placement": placement, "rng": "Philox4x32-10 on device",
-                "outputs": names, "parallelism": f"frames sharded x{world}", "dist_backend": args.dist_backend if world > 1 else None}
+                "outputs": names, "parallelism": f"frames sharded x{world}", "dist_backend": args.dist_backend if use_coll else None,
+                "collectives": (f"executed ({args.dist_backend}, world {world})" if use_coll else "none (single process)")}
         if kind == "dataset":
             Pavg = float(np.mean([int(G * d) for d in w["densities"]]))
             bytes_frame = algorithmic_bytes_per_frame(S, nsc, T, R, 0, 2, mask_bytes=4, extra=4 * 8)
@@ -480,22 +501,29 @@ def run(args):
             gemm_ms = kern.get("cgemm_w_kernel_3m", 0.0)
             flop = 8.0 * P * P * R * F                               # one right-hand side per (frame, rx): quirk Q9
             ach = flop / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
-            step_ms = dt / args.steps * 1e3
+            step_ms = dt / steps * 1e3
             hbm = bytes_frame * F / (step_ms * 1e-3) / 1e9
+            # `achieved` prices the 8 P^2 flop per right-hand side the result represents (4 real multiply-adds per complex one);
+            # the 3-multiplication form the kernel runs issues 3/4 of them on the MFMA pipe: `issued_*` is that figure
             roof = {"bound": "mfma", "achieved": ach, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": ach / MFMA_F32_PEAK_TFLOPS, "traffic": None, "kernel": "cgemm_w_kernel_3m", "kernel_ms": gemm_ms,
+                    "frac": ach / MFMA_F32_PEAK_TFLOPS, "issued_TFLOPs": 0.75 * ach, "issued_frac": 0.75 * ach / MFMA_F32_PEAK_TFLOPS,
+                    "traffic": None, "kernel": "cgemm_w_kernel_3m", "kernel_ms": gemm_ms,
                     "flop_per_frame": 8.0 * P * P * R, "kernels_ms": kern, "call_ms": call_ms,
-                    "hbm_whole_step": {"bytes_per_frame": bytes_frame, "achieved_GBps": hbm, "frac": hbm / HBM_PEAK_GBS}}
+                    "hbm_whole_step": {"bytes_per_frame": bytes_frame, "achieved_GBps": hbm, "frac": hbm / HBM_PEAK_GBS},
+                    "step_frac": hbm / HBM_PEAK_GBS}
         else:
             achieved = bytes_frame * F / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
-            traffic, tsrc = _pmc_traffic(args.workload, F, group)
+            traffic, tsrc = _pmc_traffic(workload, F, group)
+            # frac: the dominant kernel alone (algorithmic bytes / its own average duration); step_frac: the same bytes over the
+            # whole step as timed (every kernel of the step, launch gaps and -- with per-frame patterns -- the pattern kernel)
             roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": tsrc, "kernel": "frame_slab_kernel",
+                    "frac": achieved / HBM_PEAK_GBS, "step_frac": bytes_frame * F / (dt / steps) / 1e9 / HBM_PEAK_GBS,
+                    "traffic": traffic, "traffic_source": tsrc, "kernel": "frame_slab_kernel",
                     "kernel_ms": kern_ms, "taps_kernel_ms": taps_ms, "call_ms": call_ms, "bytes_per_frame": bytes_frame}
         s = summ.cpu().numpy()
         res = {
-            "metric": "OFDM frames/sec (LS+MMSE)", "value": F * world * args.steps / dt, "unit": "frames/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "metric": "OFDM frames/sec (LS+MMSE)", "value": F * world * steps / dt, "unit": "frames/s",
+            "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": dt / steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": cfgd, "roofline": roof,
         }
@@ -504,11 +532,64 @@ def run(args):
                               "nmse_db_ls": float(10 * np.log10(s[1] / s[0])), "nmse_db_mmse": float(10 * np.log10(s[2] / s[0]))}
             if kind == "fullcov":
                 res["est_mse"].pop("ls"); res["est_mse"].pop("nmse_db_ls")
-        if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(args.workload)
+        if cpu:
+            res["cpu_baseline"] = cpu_baseline(workload)
+    # hand the leg's HBM back before the next one allocates
+    del out
+    eng.close()
+    torch.cuda.empty_cache()
+    return res
+
+
+def _brief(res):
+    r = res["roofline"]
+    b = {"value": res["value"], "ms_per_step": res["ms_per_step"], "frac": r["frac"], "step_frac": r.get("step_frac"),
+         "kernel_ms": r.get("kernel_ms"), "bound": r["bound"], "frames_per_step": res["config"]["frames_per_step_per_gpu"],
+         "pattern_group": res["config"]["pattern_group"]}
+    if "plan_build_kernel_ms" in res["config"]:
+        b["pattern_kernel_ms"] = res["config"]["plan_build_kernel_ms"]
+    if r["bound"] == "mfma":
+        b["issued_frac"] = r["issued_frac"]; b["kernels_ms"] = r["kernels_ms"]
+    return b
+
+
+EXTRA_LEGS = (("cfg1_siso_epa_ls", PATTERN_GROUP), ("cfg3_4x4_etu_mmse", PATTERN_GROUP), ("cfg4_dataset_mixed", 1),
+              ("cfg5_4x4_2048_fullcov", PATTERN_GROUP))
+
+
+def run(args):
+    import torch
+    if args.selftest_spawn:
+        return _selftest_spawn(int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")))
+    job = Job(args)
+    res = measure_leg(job, args, args.workload, args.pattern_group, args.steps, args.warmup, frames=args.frames,
+                      patterns_resident=args.patterns_resident, cpu=job.world == 1 and not args.no_cpu_baseline)
+    # The default invocation (what the driver runs: BASELINE config 2, shared patterns, one GPU) also measures, after the main
+    # timed region: the same workload with the reference's own semantics -- a NEW pilot pattern per frame, drawn, triangulated
+    # and planned on the device inside every timed step (src/channel_simulator.py:390-391, src/baseline_estimators.py:65-79) --
+    # as `per_frame_patterns`, and five steps each of the other BASELINE shapes as `also`.  `value` stays the main leg's.
+    default_run = (args.workload == "cfg2_2x2_eva_ls_mmse" and args.pattern_group == PATTERN_GROUP and args.frames is None
+                   and args.patterns == "device" and not args.no_extra_legs and job.world == 1)
+    if default_run:
+        pf = measure_leg(job, args, args.workload, 1, max(5, min(args.steps, 10)), 2)
+        if job.rank == 0:
+            r = pf["roofline"]
+            res["per_frame_patterns"] = {
+                "value": pf["value"], "ms_per_step": pf["ms_per_step"], "frac": r["step_frac"],
+                "pattern_kernel_ms": pf["config"].get("plan_build_kernel_ms"), "frame_kernel_ms": r["kernel_ms"],
+                "taps_kernel_ms": r["taps_kernel_ms"], "frame_kernel_frac": r["frac"], "bytes_per_frame": r["bytes_per_frame"],
+                "plan_format": pf["config"].get("plan_format"), "steps": pf["steps"],
+                "note": "frac = bytes_per_frame x frames/s / 8 TB/s over the WHOLE step (pattern kernel + taps + frame kernel)"}
+        also = {}
+        for name, grp in EXTRA_LEGS:
+            leg = measure_leg(job, args, name, grp, 5, 2)
+            if job.rank == 0:
+                also[name] = _brief(leg)
+        if job.rank == 0:
+            res["also"] = also
+    if job.rank == 0:
         print(json.dumps(res), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
+    job.close()
 
 
 def main():
@@ -520,7 +601,8 @@ def main():
     ap.add_argument("--frames", type=int, default=None, help="frames per step per GPU (default: the config's)")
     ap.add_argument("--pattern-group", type=int, default=PATTERN_GROUP,
                     help="frames sharing one pilot pattern + interpolation plan; 1 = a new random pattern per frame as the "
-                         "reference draws them (plans built BEFORE the timed region)")
+                         "reference draws them: pilots, Delaunay triangulation and plan are then built on the device INSIDE every "
+                         "timed step (--patterns-resident pre-builds them instead)")
     ap.add_argument("--patterns-resident", action="store_true",
                     help="with --pattern-group 1 on a fixed-parameter workload: build the per-frame patterns once before the timed region")
     ap.add_argument("--patterns", default="device", choices=["device", "host"],
@@ -531,6 +613,11 @@ def main():
                     help="candidate allocations per output tensor group (1 = take the first allocation, the default; "
                          ">1 probes placements with the real kernel and keeps the fastest)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra-legs", action="store_true",
+                    help="default invocation only: skip the per_frame_patterns leg and the `also` legs of the other workloads")
+    ap.add_argument("--rccl-rehearsal", action="store_true",
+                    help="with --gpus 1: initialise the process group anyway (world size 1) and run the job's collectives "
+                         "(barrier, gather of the metric sums, max-reduction of the time, cfg5's broadcast of W) through it")
     ap.add_argument("--with-metrics", action="store_true", help="also produce the fused error sums inside the timed step")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl (= RCCL, one GPU per rank) for real runs; gloo only to rehearse the N>1 control flow with "

@@ -118,7 +118,7 @@ class MMSEEstimator:
         self.channel_covariance = channel_covariance
         self.noise_variance = noise_variance
         self.estimate_statistics = estimate_statistics
-        self._W_cache = None          # ((snr_db, content hash of the covariance, engine), W on the device)
+        self._W_cache = None          # (cheap fingerprint, (snr_db, content hash of the covariance, engine), W on the device)
 
     def estimate_covariance(self, h_ls: np.ndarray) -> np.ndarray:
         """np.cov over the flattened leading dimensions (:137-153); host-side helper nobody calls on the hot path."""
@@ -128,29 +128,52 @@ class MMSEEstimator:
     def _uses_diagonal(self):
         return self.estimate_statistics or self.channel_covariance is None
 
+    def _cov_fingerprint(self, cov):
+        """Cheap identity of the covariance object, checked on every call: the object, its storage and shape, and for a tensor
+        its in-place version counter; for an array (no version counter) the diagonal plus a strided sample of ~16 k entries.
+        The full content hash is computed only when this changes."""
+        if _is_tensor(cov):
+            return ("t", id(cov), cov.data_ptr(), tuple(cov.shape), cov._version)
+        a = np.asarray(cov)
+        flat = a.reshape(-1)
+        step = max(1, flat.size // 16384)
+        sample = np.concatenate([np.ascontiguousarray(np.diagonal(a)).reshape(-1), flat[::step]]) if a.ndim == 2 else flat[::step]
+        import hashlib
+        return ("a", id(cov), a.__array_interface__["data"][0], a.shape, str(a.dtype),
+                hashlib.blake2b(np.ascontiguousarray(sample).tobytes(), digest_size=8).digest())
+
     def _full_W(self, eng, snr_db):
         """W = R (R + sigma^2 I)^-1 on the device (float64), cached on the CONTENT of the covariance (a covariance modified
-        in place, or a new array at a recycled id, must not reuse a stale filter).  The device inverts without pivoting, which
-        is exact-arithmetic-safe for the Hermitian positive semi-definite matrices a covariance is; anything else is
-        rejected.  A singular R + sigma^2 I (non-finite W) is retried with the reference's +1e-6 I loading (:191-194) and
-        raises LinAlgError if that fails too."""
+        in place, or a new array at a recycled id, must not reuse a stale filter): a cheap fingerprint is compared on every
+        call, the full content hash only when it changed.  The device inverts without pivoting (the reference: a pivoted
+        ``np.linalg.inv``, :181-190), which is safe for Hermitian positive semi-definite matrices; Hermitian symmetry and a
+        non-negative real diagonal are ENFORCED, definiteness beyond that is the caller's contract (an indefinite Hermitian
+        matrix can meet a zero pivot and then takes the singular path below).  A singular R + sigma^2 I (non-finite W) is
+        retried with the reference's +1e-6 I loading (:191-194) and raises LinAlgError if that fails too."""
         import hashlib
-        cov = self.channel_covariance
-        cov = np.ascontiguousarray(cov.cpu().numpy() if _is_tensor(cov) else cov, dtype=np.complex128)
+        cov_obj = self.channel_covariance
+        fp = (float(snr_db), self._cov_fingerprint(cov_obj), id(eng))
+        if self._W_cache is not None and self._W_cache[0] == fp:
+            return self._W_cache[2]
+        cov = np.ascontiguousarray(cov_obj.cpu().numpy() if _is_tensor(cov_obj) else cov_obj, dtype=np.complex128)
         if cov.ndim != 2 or cov.shape[0] != cov.shape[1]:
             raise ValueError("channel_covariance must be a square P x P matrix")
         key = (float(snr_db), hashlib.blake2b(cov.tobytes(), digest_size=16).digest(), cov.shape[0], id(eng))
-        if self._W_cache is None or self._W_cache[0] != key:
+        if self._W_cache is None or self._W_cache[1] != key:
             scale = max(float(np.max(np.abs(cov))), 1e-300)
             if not np.allclose(cov, cov.conj().T, rtol=0.0, atol=1e-10 * scale):
                 raise ValueError("channel_covariance must be Hermitian (the device path inverts R + sigma^2 I without pivoting)")
+            if float(np.min(np.diagonal(cov).real)) < -1e-10 * scale:
+                raise ValueError("channel_covariance has a negative diagonal entry: not a covariance")
             W = eng.mmse_full_prepare(cov, snr_db)
             if not bool(torch.isfinite(torch.view_as_real(W)).all()):
                 W = eng.mmse_full_prepare(cov + 1e-6 * np.eye(cov.shape[0]), snr_db)
                 if not bool(torch.isfinite(torch.view_as_real(W)).all()):
                     raise np.linalg.LinAlgError("Singular matrix")
-            self._W_cache = (key, W)
-        return self._W_cache[1]
+            self._W_cache = (fp, key, W)
+        else:
+            self._W_cache = (fp, key, self._W_cache[2])
+        return self._W_cache[2]
 
     def estimate_at_pilots(self, rx_symbols, tx_pilots, pilot_mask, snr_db: float = 10):
         """MMSE filtering of the LS pilot estimates; sets ``noise_variance = 10^(-snr/10)`` (:155-196)."""

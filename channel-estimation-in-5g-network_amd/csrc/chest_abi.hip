@@ -291,6 +291,7 @@ static int pattern_set_impl(chest_ctx* ctx, int32_t slot, const int32_t* pilot_i
     PatternHost& ph = ctx->patterns[slot];
     if (ph.block) { CHEST_HIP(hipDeviceSynchronize()); CHEST_HIP(hipFree(ph.block)); }
     ph.block = blk;
+    ph.dev = PatternDev{};                                       // (a slot that held a compact plan must not keep its `pad`)
     ph.dev.slot = (const uint16_t*)(blk + o_slot);
     ph.dev.plan = with_plan ? (const void*)(blk + o_plan) : nullptr;
     ph.dev.pilot_idx = (const int32_t*)(blk + o_pil);
@@ -428,6 +429,7 @@ int chest_tune(chest_ctx* ctx, const char* key, int32_t value) {
     if (strcmp(key, "frame_rx_group") == 0) { ctx->tune_rx_group = value; return CHEST_OK; }
     if (strcmp(key, "frame_min_waves") == 0) { ctx->tune_min_waves = value; return CHEST_OK; }
     if (strcmp(key, "pattern_extra_lds") == 0) { ctx->tune_pattern_extra_lds = value < 0 ? 0 : value; return CHEST_OK; }
+    if (strcmp(key, "pattern_flip_cap") == 0) { ctx->tune_pattern_flip_cap = value < 0 ? 0 : value; return CHEST_OK; }
     set_error("chest_tune: unknown key '%s'", key);
     return CHEST_EINVAL;
 }

@@ -24,6 +24,8 @@
 //      barycentric weights; elements outside the hull get weight 0 (griddata's fill_value).
 //   'nearest': per occupied row a binary search for the closest pilot columns, minimum squared distance, ties to the
 //   smaller pilot ordinal (cKDTree's tie choice depends on its internal split order and is not reproduced).
+#include <algorithm>
+
 #include "chest_device.h"
 #include "chest_internal.h"
 
@@ -51,6 +53,7 @@ struct PatBuildArgs {
     int32_t* nbr_out;             // optional [count][2*Pcap][3]: triangle across the edge opposite each vertex, -1 on the hull
     int32_t* nsimp_out;           // optional [count]
     int32_t* status;
+    int32_t flip_cap;             // flip rounds allowed per stage (0: 4 * NT + 64, never reached); chest_tune "pattern_flip_cap"
 };
 
 struct alignas(16) TriRec { uint16_t h[6]; uint32_t claim; };
@@ -178,7 +181,7 @@ size_t pattern_build_lds_bytes(int G, int Pcap) {
     const size_t tri = (size_t)4 * Pcap + 16 + (size_t)2 * Pcap * (sizeof(uint16_t) * 6 + 4);            // pts | triangle records
     const size_t keys = (size_t)4 * (SEL_BINS + 2 * SEL_LIST);                                        // selection: histogram + threshold-bin list
     (void)G;
-    return (tri > keys ? tri : keys) + (size_t)(PB_THREADS + 8 + 3 * (PB_MAX_ROWS + 2)) * sizeof(int) + 64;
+    return (tri > keys ? tri : keys) + (size_t)(PB_THREADS + 16 + 3 * (PB_MAX_ROWS + 2)) * sizeof(int) + 64;
 }
 
 #ifdef CHEST_STAMPS
@@ -216,21 +219,17 @@ pattern_build_kernel(const PatBuildArgs A) {
 
     // ---- LDS carve-up: the key array of step 1 shares its space with the triangle arrays of steps 3-5 ----------------
     const int NT = 2 * A.Pcap;
-    int* misc = (int*)lds_raw;                                   // [PB_THREADS + 8 + 3 * (rows + 2)]
+    int* misc = (int*)lds_raw;                                   // [PB_THREADS + 16 + 3 * (rows + 2)]
     int* scan = misc;                                            // PB_THREADS + 1: workgroup scans of the pilot selection, then
-    int* cnt_s = misc + PB_THREADS + 1;                          // a few scalars
-    int* rowstart = misc + PB_THREADS + 8;                       // [rows + 1] first pilot of every row
+    int* cnt_s = misc + PB_THREADS + 1;                          // a few scalars ([6]: active triangles of the workgroup, flip rounds)
+    int* rowstart = misc + PB_THREADS + 16;                      // [rows + 1] first pilot of every row
     int* occ = rowstart + PB_MAX_ROWS + 2;                       // occupied rows
     int* toff = occ + PB_MAX_ROWS + 2;                           // first triangle of every strip
-    static_assert(4 * (PB_MAX_ROWS + 2) <= PB_THREADS, "the pocket scan's arrays live in the scan area");
-    int* stack = scan;                                           // ... the pocket scan (thread 0): chain stack,
-    uint32_t* eown = (uint32_t*)(stack + PB_MAX_ROWS + 2);       //   owner of the edge (stack[i-1], stack[i]): tri << 2 | slot, or ~0u,
-    int* eq = (int*)(eown + PB_MAX_ROWS + 2);                    //   strip of that edge if it is the bare chain edge of a strip without triangles,
-    uint32_t* rung = (uint32_t*)(eq + PB_MAX_ROWS + 2);          //   and who owns such an edge after the left pass
+    static_assert(PB_MAX_ROWS <= 32, "one lane of a wave per row (row tables, pocket scan)");
     uint32_t* pmask = (uint32_t*)scan;                           // ... and in the flip rounds [PB_THREADS]: my triangles that proposed a flip
     // (byte offsets from the LDS base, never pointer -> integer -> pointer: such a round trip loses the LDS address space and
     // every access below becomes a FLAT instruction)
-    const unsigned off_big = ((unsigned)(PB_THREADS + 8 + 3 * (PB_MAX_ROWS + 2)) * 4u + 15u) & ~15u;
+    const unsigned off_big = ((unsigned)(PB_THREADS + 16 + 3 * (PB_MAX_ROWS + 2)) * 4u + 15u) & ~15u;
     uint32_t* pts = (uint32_t*)(lds_raw + off_big);
     // one 16-B record per triangle: vertices h[0..3), neighbours across the edge opposite each vertex h[3..6), claim word
     const unsigned off_tr = (off_big + 4u * (unsigned)A.Pcap + 15u) & ~15u;
@@ -371,15 +370,24 @@ pattern_build_kernel(const PatBuildArgs A) {
     // per-row tables
     for (int r = tid; r <= S; r += PB_THREADS) rowstart[r] = count_less(pts, P, (uint32_t)r << 16);
     __syncthreads();
-    if (tid == 0) {
-        int m = 0, t = 0;
-        for (int r = 0; r < S; ++r) if (rowstart[r + 1] > rowstart[r]) occ[m++] = r;
-        for (int q = 0; q + 1 < m; ++q) {
-            toff[q] = t;
-            t += (rowstart[occ[q] + 1] - rowstart[occ[q]]) + (rowstart[occ[q + 1] + 1] - rowstart[occ[q + 1]]) - 2;
-        }
-        toff[m > 0 ? m - 1 : 0] = t;
-        cnt_s[1] = m; cnt_s[2] = t;                              // occupied rows, strip triangles
+    if (tid < 64) {
+        // occupied rows and the first triangle of every strip: lane r looks at row r (S <= 32 rows)
+        const int n_r = tid < S ? rowstart[tid + 1] - rowstart[tid] : 0;
+        const uint64_t occm = __ballot(n_r > 0);
+        const int q = __popcll(occm & ((1ull << tid) - 1ull));   // my row's rank among the occupied rows
+        const int mm = __popcll(occm);
+        if (n_r > 0) occ[q] = tid;
+        // strip q joins occupied rows q and q + 1: n_q + n_{q+1} - 2 triangles; lane q of the COMPACTED order holds n of row occ[q]
+        const int src = tid < mm ? nth_set_bit(occm, tid) : 0;
+        const int n_q = __shfl(n_r, src, 64);
+        const int n_q1 = __shfl(n_q, tid + 1 < 64 ? tid + 1 : 63, 64);
+        const int sz = tid + 1 < mm ? n_q + n_q1 - 2 : 0;
+        int incl = sz;
+#pragma unroll
+        for (int off = 1; off < 32; off <<= 1) { const int u = __shfl_up(incl, off, 64); if (tid >= off) incl += u; }
+        const int total = __shfl(incl, 31, 64);
+        if (tid < mm) toff[tid] = incl - sz;                      // (strip mm - 1 does not exist: its entry is the total)
+        if (tid == 0) { cnt_s[1] = mm; cnt_s[2] = total; }       // occupied rows (>= 1: P >= 1), strip triangles
     }
     __syncthreads();
     const int m = cnt_s[1];
@@ -461,13 +469,16 @@ pattern_build_kernel(const PatBuildArgs A) {
     }
     __syncthreads();
     PSTAMP(3);                                                   // strips
-    // pockets between the end chains and the convex hull (one thread; <= 2 (m - 2) triangles).  A monotone-chain scan over the
-    // first (left) / last (right) pilot of every occupied row; every boundary edge of the scan carries its owner (triangle,
-    // slot), so each pocket triangle is linked to its neighbours in O(1).
-    if (tid == 0) {
-        // (one thread's chain of dependent LDS operations is the whole cost here: the two topmost chain points and their
-        // positions stay in registers, a triangle record is read and written whole)
-        int nt = nstrip;
+    // pockets between the end chains and the convex hull (<= 2 (m - 2) triangles).  A monotone-chain scan over the first (left) /
+    // last (right) pilot of every occupied row; every boundary edge of the scan carries its owner (triangle, slot), so each
+    // pocket triangle is linked to its neighbours in O(1).  The scan itself is serial, but nothing in it waits for the LDS:
+    // lane q of wave 0 first fetches everything row q contributes (its two chain points, their positions, the strip triangle
+    // that owns the chain edge towards the previous row and the slot of that edge), the chain stacks live in lane registers
+    // (entry i in lane i: written by a select on the lane number, read by v_readlane with the uniform stack pointer), and the
+    // whole wave runs the scan with uniform control flow; lane 0 issues the stores (r02: one thread's chain of dependent LDS
+    // reads, 47 k cycles = a tenth of the kernel).
+    if (tid < 64) {
+        auto rd = [](uint32_t v, int i) -> uint32_t { return (uint32_t)__builtin_amdgcn_readlane((int)v, __builtin_amdgcn_readfirstlane(i)); };
         auto back_link = [&](uint32_t own, int t) {               // the owner of an edge learns its new neighbour
             if (own != 0xFFFFFFFFu) TR[own >> 2].h[3 + ((int)(own & 3u))] = (uint16_t)t;
         };
@@ -480,60 +491,69 @@ pattern_build_kernel(const PatBuildArgs A) {
             }
             return 0;
         };
-        for (int q = 0; q < m; ++q) rung[q] = 0xFFFFFFFFu;
+        const int lq = tid;
+        uint32_t P_side[2] = {0u, 0u}, PP_side[2] = {0u, 0u}, CUR_side[2] = {0xFFFFFFFFu, 0xFFFFFFFFu};
+        uint32_t EMP = 0u;                                       // strip lq - 1 has no triangle (both rows hold one pilot)
+        if (lq < m) {
+            const int r = occ[lq];
+            P_side[0] = (uint32_t)rowstart[r]; P_side[1] = (uint32_t)(rowstart[r + 1] - 1);
+            PP_side[0] = pts[P_side[0]]; PP_side[1] = pts[P_side[1]];
+            if (lq > 0) {
+                const int t0 = toff[lq - 1], nq = toff[lq] - t0;
+                if (nq > 0) {
+                    const int rp = occ[lq - 1];
+                    CUR_side[0] = ((uint32_t)t0 << 2) | (uint32_t)slot_of_edge(t0, (uint32_t)rowstart[rp], P_side[0]);
+                    CUR_side[1] = ((uint32_t)(t0 + nq - 1) << 2) | (uint32_t)slot_of_edge(t0 + nq - 1, (uint32_t)(rowstart[rp + 1] - 1), P_side[1]);
+                } else EMP = 1u;
+            }
+        }
+        uint32_t RUNG = 0xFFFFFFFFu;                              // [lane q] who took the bare chain edge of strip q on the left pass
+        int nt = nstrip;
+#pragma unroll
         for (int side = 0; side < 2; ++side) {
+            uint32_t STACK = 0u, SPOS = 0u, EOWN = 0xFFFFFFFFu, EQ = 0xFFFFFFFFu;    // [lane i] chain stack: pilot, position, edge owner, bare strip
             int sp = 0;
-            int top = 0, sec = 0;                                 // stack[sp - 1], stack[sp - 2]
-            uint32_t ptop = 0, psec = 0;                          // and their positions
+            uint32_t top = 0, sec = 0, ptop = 0, psec = 0;       // stack[sp - 1], stack[sp - 2] and their positions
             for (int q = 0; q < m; ++q) {
-                const int r = occ[q];
-                const int p = side == 0 ? rowstart[r] : rowstart[r + 1] - 1;
-                const uint32_t pp = pts[p];
-                // owner of the chain edge (previous chain point, p): the first / last triangle of strip q - 1
-                uint32_t cur = 0xFFFFFFFFu;
-                bool empty_strip = false;
-                if (q > 0) {
-                    const int t0 = toff[q - 1], nq = toff[q] - t0;
-                    if (nq > 0) {
-                        const int te = side == 0 ? t0 : t0 + nq - 1;
-                        cur = ((uint32_t)te << 2) | (uint32_t)slot_of_edge(te, (uint32_t)top, (uint32_t)p);
-                    } else { cur = rung[q - 1]; empty_strip = true; }   // both rows hold one pilot: the edge belongs to both chains
-                }
-                int cur_q = empty_strip ? q - 1 : -1;            // cur is still the bare chain edge of that (triangle-less) strip
+                const uint32_t p = rd(P_side[side], q), pp = rd(PP_side[side], q);
+                uint32_t cur = rd(CUR_side[side], q);            // owner of the chain edge (previous chain point, p)
+                uint32_t cur_q = 0xFFFFFFFFu;                    // cur is still the bare chain edge of that (triangle-less) strip
+                if (rd(EMP, q) != 0u) { cur = rd(RUNG, q - 1); cur_q = (uint32_t)(q - 1); }    // the edge belongs to both chains
                 while (sp >= 2) {
                     const int o = orient2(psec, ptop, pp);
                     // the top point lies in a pocket if it is on the inner side of sec -> p (left chain: o < 0, right chain: o > 0)
                     if (!(side == 0 ? o < 0 : o > 0)) break;
                     // counter-clockwise: (a, p, b) on the left chain, (a, b, p) on the right one; a = sec, b = top
                     const int t = nt++;
-                    const uint32_t own_ab = eown[sp - 1];
+                    const uint32_t own_ab = rd(EOWN, sp - 1);
                     const uint32_t n_ab = own_ab != 0xFFFFFFFFu ? own_ab >> 2 : TNONE, n_bp = cur != 0xFFFFFFFFu ? cur >> 2 : TNONE;
                     // edge (b, p) is opposite a (slot 0); edge (a, b) is opposite p: slot 1 on the left chain, 2 on the right one;
                     // edge (a, p), opposite b, is the new chain edge: its neighbour comes later
                     const int s_ab = side == 0 ? 1 : 2, s_ap = side == 0 ? 2 : 1;
-                    st_tri(TR, (uint32_t)t, (uint32_t)sec, (uint32_t)(side == 0 ? p : top), (uint32_t)(side == 0 ? top : p),
-                           n_bp, side == 0 ? n_ab : TNONE, side == 0 ? TNONE : n_ab, 0u);
-                    back_link(own_ab, t);
-                    back_link(cur, t);
+                    if (lq == 0) {
+                        st_tri(TR, (uint32_t)t, sec, side == 0 ? p : top, side == 0 ? top : p,
+                               n_bp, side == 0 ? n_ab : TNONE, side == 0 ? TNONE : n_ab, 0u);
+                        back_link(own_ab, t);
+                        back_link(cur, t);
+                    }
                     // a chain edge shared by both chains (strip without triangles): remember who took it on the left pass
                     if (side == 0) {
-                        const int e = eq[sp - 1];
-                        if (e >= 0) rung[e] = ((uint32_t)t << 2) | (uint32_t)s_ab;
-                        if (cur_q >= 0) rung[cur_q] = ((uint32_t)t << 2) | 0u;
+                        const uint32_t e = rd(EQ, sp - 1);
+                        if (e != 0xFFFFFFFFu && (uint32_t)lq == e) RUNG = ((uint32_t)t << 2) | (uint32_t)s_ab;
+                        if (cur_q != 0xFFFFFFFFu && (uint32_t)lq == cur_q) RUNG = ((uint32_t)t << 2) | 0u;
                     }
-                    cur_q = -1;
+                    cur_q = 0xFFFFFFFFu;
                     cur = ((uint32_t)t << 2) | (uint32_t)s_ap;
                     --sp;
                     top = sec; ptop = psec;
-                    if (sp >= 2) { sec = stack[sp - 2]; psec = pts[sec]; }
+                    if (sp >= 2) { sec = rd(STACK, sp - 2); psec = rd(SPOS, sp - 2); }
                 }
-                eown[sp] = cur;
-                eq[sp] = cur_q;
-                stack[sp++] = p;
+                if (lq == sp) { EOWN = cur; EQ = cur_q; STACK = p; SPOS = pp; }
+                ++sp;
                 sec = top; psec = ptop; top = p; ptop = pp;
             }
         }
-        cnt_s[2] = nt;
+        if (lq == 0) cnt_s[2] = nt;
     }
     __syncthreads();
     const int ntri = cnt_s[2];
@@ -543,148 +563,233 @@ pattern_build_kernel(const PatBuildArgs A) {
     // Rounds of independent flips.  A triangle is ACTIVE (its claim word starts the round as CLAIM_DIRTY) if it changed or lost a
     // claim in the previous round; everything is active at first.  Only active triangles test their edges -- an edge between
     // two active triangles from the smaller index -- so once the bulk of the flips is done a round costs one cheap pass.
-    // Every thread keeps the active set of its own triangles (t = tid + 256 i) as a register bit mask.
     // claim word: CLAIM_NONE / CLAIM_DIRTY (inactive / active, unclaimed), the smallest key (4 t + edge < 2^18) of the edges that
     // claimed the triangle, or that key | CLAIM_WON once the edge has flipped: the two triangles of a flip find each other
     // through it (the owner t keeps its partner in neighbour slot 1, the partner keeps t in slot 2)
+    //
+    // A round is three phases that must not overlap (test + claim | rewrite | relink), and the kernel is bound by the
+    // instructions it issues: a phase costs a wave its ~200-350 instructions whether 64 of its lanes have a triangle or two.
+    // The active set shrinks fast (P = 838: 1 545, 623, 705, 598, 554, 376, 277, 167, 92, 57, 27, 16, 2 triangles per round,
+    // tools/delaunay_model.py), so the rounds run in two stages:
+    //   stage 0  all four waves, every thread the triangles t = tid + 256 i, phases separated by workgroup barriers -- while
+    //            the workgroup's active set is worth four waves;
+    //   stage 1  from FLIP_SOLO_AT active triangles on (and at most 2 048 triangles in all: 32 mask bits per lane), wave 0 alone
+    //            takes every triangle (t = lane + 64 i) and finishes WITHOUT barriers -- the LDS executes a wave's operations in
+    //            issue order, so program order separates the phases -- while the other three waves wait at the stage's end
+    //            and issue nothing (r03 stamps: 8 of 14 rounds; a third of the kernel's instructions).
+    // Both stages flip by the same rules, so the triangulation does not depend on where the switch happens.
     constexpr uint32_t CLAIM_NONE = 0xFFFFFFFFu, CLAIM_DIRTY = 0xFFFFFFFEu, CLAIM_WON = 0x40000000u;
-    const int lane = tid & 63, wbase = tid & ~63;
-    uint32_t active = 0;
-    for (int i = 0, t = tid; t < ntri; t += PB_THREADS, ++i) { TR[t].claim = CLAIM_DIRTY; active |= 1u << i; }
+    constexpr int FLIP_SOLO_AT = 192;
+    const int lane = tid & 63, wave = tid >> 6, wbase = tid & ~63;
+    const int round_cap = A.flip_cap > 0 ? A.flip_cap : 4 * NT + 64;
+    const bool can_solo = ntri <= 2048 && PB_THREADS == 256;
+    // [64] hand-over to stage 1 and its per-round set of claimed triangles (bit t >> 6 of word t & 63) -- in the row tables'
+    // place, which are dead once the pockets are filled (the LDS granule is 1 280 B: 25 granules = 32 000 B per workgroup is
+    // what lets five workgroups share a CU)
+    uint32_t* gmask = (uint32_t*)rowstart;
+    static_assert(2 * (PB_MAX_ROWS + 2) >= 64, "gmask takes the place of rowstart + occ");
     pmask[tid] = 0;
-    if (tid == 0) cnt_s[3] = 0;
-    __syncthreads();
+    if (tid < 64) gmask[tid] = 0;
+    if (tid == 0) { cnt_s[3] = 0; cnt_s[6] = 0; }
 #ifdef CHEST_STAMPS
     unsigned dbg_rounds = 0, dbg_cross = 0;
     unsigned long long dbg_ph[4] = {0, 0, 0, 0}, dbg_t = __builtin_amdgcn_s_memtime();
 #define DBG_PH(i) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); dbg_ph[i] += n_ - dbg_t; dbg_t = n_; } while (0)
+    // inside the test phase of the one-wave stage (slots 12..15 of the record): record read | neighbours + pilots read | opposite
+    // pilots read + in-circle tests + claims | everything drained; each stamp behind a forced wait for the LDS
+    unsigned long long dbg_p0[4] = {0, 0, 0, 0}, dbg_u = 0;
+    unsigned dbg_solo_rounds = 0;
+#define DBG_P0(i) do { if (solo) { __builtin_amdgcn_s_waitcnt(0xc07f); const unsigned long long n_ = __builtin_amdgcn_s_memtime(); dbg_p0[i] += n_ - dbg_u; dbg_u = n_; } } while (0)
 #else
 #define DBG_PH(i) do { } while (0)
+#define DBG_P0(i) do { } while (0)
 #endif
-    // The triangles of a thread are t = tid + PB_THREADS * bit; in every phase the wave's work items are dealt evenly to its
-    // lanes (wave_balanced), whoever owns them.
-    for (int round = 0; round < 4 * NT + 64; ++round) {
-#ifdef CHEST_STAMPS
-        ++dbg_rounds;
-#endif
-        // phase 0: active triangles test their edges; an edge that fails the in-circle test claims both of its triangles.
-        // One 16-B read brings a triangle; the three neighbours and then the three opposite pilots are fetched together.
-        wave_balanced(active, lane, [&](int owner, int bit) {
-            const int t = wbase + owner + PB_THREADS * bit;
-            const TriU T0 = ld_tri(TR, (uint32_t)t);
-            const uint32_t pv[3] = {pts[T0.v[0]], pts[T0.v[1]], pts[T0.v[2]]};
-            TriU U[3];
-#pragma unroll
-            for (int i = 0; i < 3; ++i) U[i] = ld_tri(TR, T0.n[i] == TNONE ? (uint32_t)t : T0.n[i]);
-            uint32_t pd[3];
-            bool need[3];
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                const uint32_t u = T0.n[i];
-                need[i] = !(u == TNONE || (u < (uint32_t)t && U[i].claim != CLAIM_NONE));       // else the other (active) side tests it
-                const uint32_t b = T0.v[(i + 1) % 3], c = T0.v[(i + 2) % 3];
-                const uint32_t d = (U[i].v[0] != b && U[i].v[0] != c) ? U[i].v[0] : ((U[i].v[1] != b && U[i].v[1] != c) ? U[i].v[1] : U[i].v[2]);
-                pd[i] = pts[need[i] ? d : T0.v[i]];
+    uint32_t active = 0;
+    for (int i = 0, t = tid; t < ntri; t += PB_THREADS, ++i) { TR[t].claim = CLAIM_DIRTY; active |= 1u << i; }
+    __syncthreads();
+    int round = 0;
+    bool done = false;                                            // no edge left to flip
+    for (int stage = 0; stage < 2 && !done; ++stage) {
+        const bool solo = stage == 1;
+        const int istride = solo ? 64 : PB_THREADS, ilane = solo ? lane : tid, ibase = solo ? 0 : wbase;
+        auto sync = [&]() {                                       // phase boundary
+            if (solo) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");     // program order = LDS order inside a wave
+            else __syncthreads();
+        };
+        if (solo) {
+            // hand-over: everybody's active triangles into wave 0's masks
+            for (uint32_t mm = active; mm != 0; mm &= mm - 1) {
+                const uint32_t t = (uint32_t)(tid + PB_THREADS * (__ffs(mm) - 1));
+                atomicOr(&gmask[t & 63u], 1u << (t >> 6));
             }
-            bool proposed = false;
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                if (need[i] && incircle(pv[i], pv[(i + 1) % 3], pv[(i + 2) % 3], pd[i]) > 0) {
-                    const uint32_t key = (uint32_t)t * 4u + (uint32_t)i;
-                    atomicMin(&TR[t].claim, key);
-                    atomicMin(&TR[T0.n[i]].claim, key);
-                    proposed = true;
-                }
-            }
-            if (proposed) { atomicOr(&pmask[wbase + owner], 1u << bit); cnt_s[3] = 1; }
-        });
-        __syncthreads();
-        DBG_PH(0);
-        if (cnt_s[3] == 0) break;
-        // phase 1: winners (an edge that holds the claim on both of its triangles) rewrite the two triangles; outer neighbours
-        // keep their OLD ids for now.  Only triangles that proposed can own a winning edge.
-        const uint32_t proposed = pmask[tid];
-        wave_balanced(proposed, lane, [&](int owner, int bit) {
-            const int t = wbase + owner + PB_THREADS * bit;
-            const TriU T0 = ld_tri(TR, (uint32_t)t);
-            const uint32_t key = T0.claim;
-            if ((key >> 2) != (uint32_t)t) return;               // the winning edge of t was tested from another triangle
-            // (run-time subscripts into the register copies of a record would put them in scratch memory: selects instead)
-            const int i = (int)(key & 3u);
-            const uint32_t u = sel3(T0.n, i);
-            const TriU U0 = ld_tri(TR, u);
-            if (U0.claim != key) return;
-            const uint32_t a = sel3(T0.v, i), b = sel3(T0.v, i + 1), c = sel3(T0.v, i + 2);
-            const uint32_t n_ab = sel3(T0.n, i + 2), n_ca = sel3(T0.n, i + 1);
-            const int jd = (U0.v[0] != b && U0.v[0] != c) ? 0 : ((U0.v[1] != b && U0.v[1] != c) ? 1 : 2);
-            const uint32_t d = sel3(U0.v, jd);
-            // u = (d, c, b) rotated so that u[jd] = d: the edge opposite c is (b, d), the edge opposite b is (d, c)
-            const uint32_t n_db = sel3(U0.n, jd + 1), n_cd = sel3(U0.n, jd + 2);
-            st_tri(TR, (uint32_t)t, a, b, d, n_db, u, n_ab, key | CLAIM_WON);
-            st_tri(TR, u, a, d, c, n_cd, n_ca, (uint32_t)t, key | CLAIM_WON);
-        });
-        __syncthreads();
-        DBG_PH(1);
-        // phase 2: the owner of every flip resolves the outer neighbours of its two new triangles (the old neighbour, or its
-        // partner if that one flipped too) and writes the back-pointer of neighbours that did not flip
-        uint32_t won = 0;                                        // my triangles that own a flip of this round (claim = own key | CLAIM_WON)
-        for (uint32_t m = proposed; m != 0; m &= m - 1) {
-            const int bit = __ffs(m) - 1;
-            const uint32_t c = TR[tid + PB_THREADS * bit].claim;
-            if ((c & 0xC0000000u) == CLAIM_WON && ((c & ~CLAIM_WON) >> 2) == (uint32_t)(tid + PB_THREADS * bit)) won |= 1u << bit;
+            __syncthreads();
+            if (wave != 0) break;
+            active = gmask[lane];
+            gmask[lane] = 0;                                      // from here on: the round's claimed triangles
+            pmask[lane] = 0;
+            sync();
         }
-        wave_balanced(won, lane, [&](int owner, int bit) {
-            const int t = wbase + owner + PB_THREADS * bit;
-            const TriU Tt = ld_tri(TR, (uint32_t)t);
-            const uint32_t pT = Tt.n[1];
-            const TriU Tp = ld_tri(TR, pT);
+        for (; round < round_cap; ++round) {
+#ifdef CHEST_STAMPS
+            ++dbg_rounds;
+#endif
+            // phase 0: active triangles test their edges; an edge that fails the in-circle test claims both of its triangles.
+            // One 16-B read brings a triangle; the three neighbours and then the three opposite pilots are fetched together.
+#ifdef CHEST_STAMPS
+            if (solo) { ++dbg_solo_rounds; dbg_u = __builtin_amdgcn_s_memtime(); }
+#endif
+            wave_balanced(active, lane, [&](int owner, int bit) {
+                const uint32_t t = (uint32_t)(ibase + owner + istride * bit);
+                const TriU T0 = ld_tri(TR, t);
+                DBG_P0(0);
+                const uint32_t pv[3] = {pts[T0.v[0]], pts[T0.v[1]], pts[T0.v[2]]};
+                TriU U[3];
 #pragma unroll
-            for (int side = 0; side < 2; ++side) {
-                const uint32_t X = side == 0 ? (uint32_t)t : pT;
-                const uint32_t pX = side == 0 ? pT : (uint32_t)t;
-                const TriU TX = side == 0 ? Tt : Tp;
-                TriU TY[3];
-                uint32_t pY[3];
+                for (int i = 0; i < 3; ++i) U[i] = ld_tri(TR, T0.n[i] == TNONE ? t : T0.n[i]);
+                DBG_P0(1);
+                uint32_t pd[3];
+                bool need[3];
 #pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    const uint32_t Y = (TX.n[k] == TNONE || TX.n[k] == pX) ? X : TX.n[k];
-                    TY[k] = ld_tri(TR, Y);
-                    const uint32_t cy = TY[k].claim;             // flipped in this round: its partner, else TNONE
-                    pY[k] = (cy & 0xC0000000u) == CLAIM_WON ? ((((cy & ~CLAIM_WON) >> 2) == Y) ? TY[k].n[1] : TY[k].n[2]) : TNONE;
+                for (int i = 0; i < 3; ++i) {
+                    const uint32_t u = T0.n[i];
+                    need[i] = !(u == TNONE || (u < t && U[i].claim != CLAIM_NONE));       // else the other (active) side tests it
+                    const uint32_t b = T0.v[(i + 1) % 3], c = T0.v[(i + 2) % 3];
+                    const uint32_t d = (U[i].v[0] != b && U[i].v[0] != c) ? U[i].v[0] : ((U[i].v[1] != b && U[i].v[1] != c) ? U[i].v[1] : U[i].v[2]);
+                    pd[i] = pts[need[i] ? d : T0.v[i]];
                 }
+                bool proposed = false;
 #pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    uint32_t Y = TX.n[k];
-                    if (Y == TNONE || Y == pX) continue;
-                    const uint32_t x = TX.v[(k + 1) % 3], y = TX.v[(k + 2) % 3];
-                    const uint32_t y0 = TY[k].v[0], y1 = TY[k].v[1], y2 = TY[k].v[2];
-                    if (pY[k] != TNONE) {
-                        const bool has = (y0 == x || y1 == x || y2 == x) && (y0 == y || y1 == y || y2 == y);
-                        if (!has) Y = pY[k];
-                        TR[X].h[3 + k] = (uint16_t)Y;
-                    } else {
-                        const int k2 = (y0 != x && y0 != y) ? 0 : ((y1 != x && y1 != y) ? 1 : 2);
-                        TR[Y].h[3 + k2] = (uint16_t)X;
+                for (int i = 0; i < 3; ++i) {
+                    if (need[i] && incircle(pv[i], pv[(i + 1) % 3], pv[(i + 2) % 3], pd[i]) > 0) {
+                        const uint32_t key = t * 4u + (uint32_t)i;
+                        atomicMin(&TR[t].claim, key);
+                        atomicMin(&TR[T0.n[i]].claim, key);
+                        proposed = true;
+                        // stage 1 keeps the round's CLAIMED triangles in gmask so that the end of the round visits them instead
+                        // of scanning all the triangles the one wave owns
+                        if (solo) atomicOr(&gmask[T0.n[i] & 63u], 1u << (T0.n[i] >> 6));
                     }
                 }
+                if (proposed) {
+                    atomicOr(&pmask[ibase + owner], 1u << bit);
+                    if (solo) atomicOr(&gmask[t & 63u], 1u << (t >> 6)); else cnt_s[3] = 1;
+                }
+                DBG_P0(2);
+            });
+            sync();
+            DBG_P0(3);
+            DBG_PH(0);
+            const uint32_t proposed = pmask[ilane];
+            if (solo ? __ballot(proposed != 0) == 0 : cnt_s[3] == 0) { done = true; break; }
+            // phase 1: winners (an edge that holds the claim on both of its triangles) rewrite the two triangles; outer neighbours
+            // keep their OLD ids for now.  Only triangles that proposed can own a winning edge.
+            wave_balanced(proposed, lane, [&](int owner, int bit) {
+                const uint32_t t = (uint32_t)(ibase + owner + istride * bit);
+                const TriU T0 = ld_tri(TR, t);
+                const uint32_t key = T0.claim;
+                if ((key >> 2) != t) return;                     // the winning edge of t was tested from another triangle
+                // (run-time subscripts into the register copies of a record would put them in scratch memory: selects instead)
+                const int i = (int)(key & 3u);
+                const uint32_t u = sel3(T0.n, i);
+                const TriU U0 = ld_tri(TR, u);
+                if (U0.claim != key) return;
+                const uint32_t a = sel3(T0.v, i), b = sel3(T0.v, i + 1), c = sel3(T0.v, i + 2);
+                const uint32_t n_ab = sel3(T0.n, i + 2), n_ca = sel3(T0.n, i + 1);
+                const int jd = (U0.v[0] != b && U0.v[0] != c) ? 0 : ((U0.v[1] != b && U0.v[1] != c) ? 1 : 2);
+                const uint32_t d = sel3(U0.v, jd);
+                // u = (d, c, b) rotated so that u[jd] = d: the edge opposite c is (b, d), the edge opposite b is (d, c)
+                const uint32_t n_db = sel3(U0.n, jd + 1), n_cd = sel3(U0.n, jd + 2);
+                st_tri(TR, t, a, b, d, n_db, u, n_ab, key | CLAIM_WON);
+                st_tri(TR, u, a, d, c, n_cd, n_ca, t, key | CLAIM_WON);
+            });
+            if (tid == 0 && !solo) cnt_s[6] = 0;                 // (read after the round's last barrier, added to after this one)
+            sync();
+            DBG_PH(1);
+            // phase 2: the owner of every flip resolves the outer neighbours of its two new triangles (the old neighbour, or its
+            // partner if that one flipped too) and writes the back-pointer of neighbours that did not flip
+            uint32_t won = 0;                                    // my triangles that own a flip of this round (claim = own key | CLAIM_WON)
+            for (uint32_t mm = proposed; mm != 0; mm &= mm - 1) {
+                const int bit = __ffs(mm) - 1;
+                const uint32_t t = (uint32_t)(ilane + istride * bit);
+                const uint32_t c = TR[t].claim;
+                if ((c & 0xC0000000u) == CLAIM_WON && ((c & ~CLAIM_WON) >> 2) == t) won |= 1u << bit;
             }
-        });
-        __syncthreads();
-        DBG_PH(2);
-        // claimed triangles (flipped, or candidates that lost) are the next round's active set; marks that drew no claim clear
-        active = 0;
-        for (int i = 0, t = tid; t < ntri; t += PB_THREADS, ++i) {
-            const uint32_t c = TR[t].claim;
-            if (c == CLAIM_NONE) continue;
-            const bool act = c < CLAIM_DIRTY;
-            TR[t].claim = act ? CLAIM_DIRTY : CLAIM_NONE;
-            if (act) active |= 1u << i;
+            wave_balanced(won, lane, [&](int owner, int bit) {
+                const uint32_t t = (uint32_t)(ibase + owner + istride * bit);
+                const TriU Tt = ld_tri(TR, t);
+                const uint32_t pT = Tt.n[1];
+                const TriU Tp = ld_tri(TR, pT);
+#pragma unroll
+                for (int side = 0; side < 2; ++side) {
+                    const uint32_t X = side == 0 ? t : pT;
+                    const uint32_t pX = side == 0 ? pT : t;
+                    const TriU TX = side == 0 ? Tt : Tp;
+                    TriU TY[3];
+                    uint32_t pY[3];
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        const uint32_t Y = (TX.n[k] == TNONE || TX.n[k] == pX) ? X : TX.n[k];
+                        TY[k] = ld_tri(TR, Y);
+                        const uint32_t cy = TY[k].claim;         // flipped in this round: its partner, else TNONE
+                        pY[k] = (cy & 0xC0000000u) == CLAIM_WON ? ((((cy & ~CLAIM_WON) >> 2) == Y) ? TY[k].n[1] : TY[k].n[2]) : TNONE;
+                    }
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        uint32_t Y = TX.n[k];
+                        if (Y == TNONE || Y == pX) continue;
+                        const uint32_t x = TX.v[(k + 1) % 3], y = TX.v[(k + 2) % 3];
+                        const uint32_t y0 = TY[k].v[0], y1 = TY[k].v[1], y2 = TY[k].v[2];
+                        if (pY[k] != TNONE) {
+                            const bool has = (y0 == x || y1 == x || y2 == x) && (y0 == y || y1 == y || y2 == y);
+                            if (!has) Y = pY[k];
+                            TR[X].h[3 + k] = (uint16_t)Y;
+                        } else {
+                            const int k2 = (y0 != x && y0 != y) ? 0 : ((y1 != x && y1 != y) ? 1 : 2);
+                            TR[Y].h[3 + k2] = (uint16_t)X;
+                        }
+                    }
+                }
+            });
+            sync();
+            DBG_PH(2);
+            // claimed triangles (flipped, or candidates that lost) are the next round's active set; marks that drew no claim clear
+            if (solo) {
+                uint32_t next = 0;
+                for (uint32_t mm = active | gmask[lane]; mm != 0; mm &= mm - 1) {       // this round's active and claimed triangles
+                    const int i = __ffs(mm) - 1;
+                    const uint32_t t = (uint32_t)(lane + 64 * i);
+                    const bool act = TR[t].claim < CLAIM_DIRTY;
+                    TR[t].claim = act ? CLAIM_DIRTY : CLAIM_NONE;
+                    if (act) next |= 1u << i;
+                }
+                gmask[lane] = 0;
+                active = next;
+            } else {
+                active = 0;
+                for (int i = 0, t = tid; t < ntri; t += PB_THREADS, ++i) {
+                    const uint32_t c = TR[t].claim;
+                    if (c == CLAIM_NONE) continue;
+                    const bool act = c < CLAIM_DIRTY;
+                    TR[t].claim = act ? CLAIM_DIRTY : CLAIM_NONE;
+                    if (act) active |= 1u << i;
+                }
+                if (can_solo) {                                   // the workgroup's active triangles
+                    int c = __popc(active);
+#pragma unroll
+                    for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off, 64);
+                    if (lane == 0) atomicAdd(&cnt_s[6], c);
+                }
+                if (tid == 0) cnt_s[3] = 0;
+            }
+            pmask[ilane] = 0;
+            sync();
+            DBG_PH(3);
+            if (!solo && can_solo && cnt_s[6] <= FLIP_SOLO_AT) { ++round; break; }       // few enough for one wave: stage 1
         }
-        pmask[tid] = 0;
-        if (tid == 0) cnt_s[3] = 0;
-        __syncthreads();
-        DBG_PH(3);
+        if (!solo && !can_solo) break;
     }
+    if (!done && round >= round_cap && (tid & 63) == 0) atomicExch(A.status, 3);      // ran into the round limit: not a finished triangulation
+    __syncthreads();
 
     PSTAMP(5);                                                   // flips
     if (A.simp_out != nullptr) {
@@ -831,6 +936,8 @@ pattern_build_kernel(const PatBuildArgs A) {
             unsigned long long* d_ = g_pat_stamp + (size_t)blockIdx.x * 16;
             d_[7] = (unsigned long long)dbg_rounds | ((unsigned long long)dbg_cross << 32);
             for (int i_ = 0; i_ < 4; ++i_) d_[8 + i_] = dbg_ph[i_];
+            for (int i_ = 0; i_ < 4; ++i_) d_[12 + i_] = dbg_p0[i_];
+            d_[7] |= (unsigned long long)dbg_solo_rounds << 56;
         }
     }
 #endif
@@ -885,7 +992,18 @@ extern "C" int chest_patterns_build(chest_ctx* ctx, void* stream, int32_t first_
         for (auto it = ctx->pools.begin(); it != ctx->pools.end();) {
             const bool overlap = it->first_slot < first_slot + count && first_slot < it->first_slot + it->count;
             if (overlap) {
-                for (int s = it->first_slot; s < it->first_slot + it->count && s < (int)ctx->patterns.size(); ++s) ctx->patterns[s] = PatternHost{};
+                // every slot of the old pool loses its storage: host entries AND the device table entries (a descriptor naming a
+                // released slot must be flagged CHEST_FRAME_BAD_DESC, not read freed memory); slots that were re-set through
+                // chest_pattern_set since own their block and stay
+                const int s_end = std::min(it->first_slot + it->count, (int)ctx->patterns.size());
+                for (int s = it->first_slot; s < s_end;) {
+                    if (ctx->patterns[s].block != nullptr) { ++s; continue; }
+                    int e = s;                                   // run of released slots [s, e)
+                    while (e < s_end && ctx->patterns[e].block == nullptr) ctx->patterns[e++] = PatternHost{};
+                    const int dev_e = std::min(e, ctx->pattern_cap);
+                    if (s < dev_e) CHEST_HIP(hipMemset(ctx->d_patterns + s, 0, (size_t)(dev_e - s) * sizeof(PatternDev)));
+                    s = e;
+                }
                 (void)hipFree(it->block); (void)hipFree(it->d_meta);
                 it = ctx->pools.erase(it);
             } else ++it;
@@ -934,6 +1052,7 @@ extern "C" int chest_patterns_build(chest_ctx* ctx, void* stream, int32_t first_
     a.num_pilots = d_np; a.given_idx = pilot_idx; a.pattern_ids = d_ids; a.seed = seed; a.idx_stride = idx_stride;
     a.first_slot = first_slot; a.S = ctx->fp.S; a.nsc = ctx->fp.nsc; a.method = method; a.Pcap = pool->Pcap;
     a.simp_out = simplices_out; a.nbr_out = simplices_out ? neighbors_out : nullptr; a.nsimp_out = num_simplices_out; a.status = ctx->d_status;
+    a.flip_cap = ctx->tune_pattern_flip_cap;
     if (simplices_out && pool->Pcap != Pmax) { set_error("chest_patterns_build: simplices_out needs a fresh slot range (row stride is 2*Pmax*3)"); return CHEST_EINVAL; }
     const size_t lds_run = pattern_build_lds_bytes(G, pool->Pcap) + (size_t)ctx->tune_pattern_extra_lds;
     const int sp = prof_open(ctx, st, CHEST_K_PLAN);
@@ -950,6 +1069,10 @@ extern "C" int chest_patterns_build(chest_ctx* ctx, void* stream, int32_t first_
     for (int i = 0; i < count; ++i) {
         PatternHost& ph = ctx->patterns[first_slot + i];
         unsigned char* base = (unsigned char*)pool->block + (size_t)i * pool->stride;
+        if (ph.block != nullptr) {                               // set through chest_pattern_set since the pool was made: the pool takes
+            CHEST_HIP(hipStreamSynchronize(st));                 // the slot back (frames already launched may still read the old block)
+            (void)hipFree(ph.block);
+        }
         ph.block = nullptr;                                      // owned by the pool
         ph.dev.slot = (const uint16_t*)base;
         ph.dev.plan = method >= 0 ? (const void*)(base + pool->o_plan) : nullptr;

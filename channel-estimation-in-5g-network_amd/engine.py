@@ -233,6 +233,11 @@ class Engine:
                                              None if simp is None else simp.data_ptr(), None if cnt is None else cnt.data_ptr(),
                                              None if nbr is None else nbr.data_ptr()),
                 "chest_patterns_build")
+        # the slots now hold other patterns: drop what pattern_slot() cached for them (a later hit would return a slot whose
+        # pilots and plan belong to a different pattern)
+        lo, hi = int(first_slot), int(first_slot) + count
+        for key in [k for k, s in self._slots.items() if lo <= s < hi]:
+            del self._slots[key]
         for i in range(count):
             self._slot_P[int(first_slot) + i] = int(npil[i])
         self._next_slot = max(self._next_slot, int(first_slot) + count)
@@ -255,6 +260,8 @@ class Engine:
             raise N.ChestError("a kernel met an invalid frame descriptor (channel_type or pattern_slot)")
         if st.value == 2:
             raise N.ChestError("estimates were requested for a pattern that has no interpolation plan")
+        if st.value == 3:
+            raise N.ChestError("a pattern's Delaunay flips ran into their round limit: its plan is not guaranteed to be the Delaunay one")
 
     def profile_begin(self, capacity: int):
         """Record HIP events around the taps and frame kernels of the next `capacity` run_frames calls."""
@@ -278,7 +285,8 @@ class Engine:
         return res
 
     def tune(self, key: str, value: int):
-        """Experiment knobs of the library (tools only): 'frame_rx_group', 'frame_min_waves', 'pattern_extra_lds'."""
+        """Experiment knobs of the library (tools only): 'frame_rx_group', 'frame_min_waves', 'pattern_extra_lds',
+        'pattern_flip_cap'."""
         N.check(N.lib().chest_tune(self._h, key.encode(), int(value)), "chest_tune")
 
     # ---- helpers ----------------------------------------------------------------------------------

@@ -4,7 +4,7 @@ Frames are independent: every random draw of frame i is a pure function of (seed
 contiguous split of [0, total) over the ranks produces exactly the frames a single GPU would
 (reference loop: src/dataset_generator.py:112-125, which is sequential only because it shares one
 global RNG).  There is no collective on the data path; the job ends with ONE gather of the small
-per-frame metadata / metric records (36 + 8 bytes per frame) to rank 0.
+per-frame metadata / metric records (36 + 8 bytes per frame, one packed block per rank) to rank 0.
 """
 from __future__ import annotations
 
@@ -41,14 +41,21 @@ def frame_choices(seed: int, frame_index: np.ndarray, num_options):
     return out
 
 
-def gather_records(local: "np.ndarray", frame_index: "np.ndarray" = None, dst: int = 0, all_ranks: bool = False, group=None):
-    """The job's single collective: every rank's per-frame records (float32 [n_local, C]) and, separately, their GLOBAL
-    frame indices as int64 (float32 is exact only below 2^24 frames), concatenated in rank order.
+def gather_records(local: "np.ndarray", frame_index: "np.ndarray" = None, dst: int = 0, all_ranks: bool = False, group=None,
+                   capacity: int = None, force_collective: bool = False):
+    """The job's single collective: every rank's per-frame records (float32 [n_local, C]) together with their GLOBAL frame
+    indices (int64: float32 is exact only below 2^24 frames), concatenated in rank order.
 
-    Default: a ``gather`` to rank ``dst`` (the north-star's "single gather at the end"); the other ranks get
-    ``(None, None)``.  ``all_ranks=True`` makes it an ``all_gather`` for jobs in which every rank needs the summary.
-    Ragged shard sizes are padded to the largest one.  Works on CPU (gloo) and GPU (nccl = RCCL) process groups; without
-    an initialised group it returns the local arrays."""
+    ONE collective carries everything: each rank sends an int32 block [capacity + 1, C + 2] -- row 0 holds its record count,
+    the rows after it the float32 records bit-cast to int32 (the transport moves bytes, it does no arithmetic) followed by the
+    low and high halves of the frame index.  ``capacity`` is the largest shard size; jobs that shard with ``shard_range``
+    know it without talking (``ceil(total / world)``) and pass it.  Without it the sizes are agreed by one extra 8-byte
+    all-gather first.
+
+    Default: a ``gather`` to rank ``dst`` -- ``dst`` is a rank OF ``group`` (the default group: the global rank) -- the
+    other ranks get ``(None, None)``.  ``all_ranks=True`` makes it an ``all_gather``.  Works on CPU (gloo) and GPU
+    (nccl = RCCL) process groups.  Without an initialised group, or in a group of one, the local arrays are returned
+    unless ``force_collective`` asks for the collective to run anyway (the one-rank RCCL rehearsal)."""
     import torch
     import torch.distributed as dist
     local = np.asarray(local, dtype=np.float32)
@@ -57,49 +64,59 @@ def gather_records(local: "np.ndarray", frame_index: "np.ndarray" = None, dst: i
     ids = np.arange(len(local), dtype=np.int64) if frame_index is None else np.asarray(frame_index, dtype=np.int64)
     if len(ids) != len(local):
         raise ValueError("frame_index and records differ in length")
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    ready = dist.is_available() and dist.is_initialized()
+    if not ready or (dist.get_world_size(group) == 1 and not force_collective):
         return local, ids
     world, rank = dist.get_world_size(group), dist.get_rank(group)
+    if not (0 <= dst < world):
+        raise ValueError(f"dst {dst} is not a rank of the group (size {world})")
     backend = dist.get_backend(group)
     dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
-    n = torch.tensor([local.shape[0]], dtype=torch.int64, device=dev)
-    counts = [torch.zeros_like(n) for _ in range(world)]
-    dist.all_gather(counts, n, group=group)                           # 8 bytes per rank: the shard sizes
-    counts = [int(c.item()) for c in counts]
-    width, cap = local.shape[1], max(counts)
-    rec = torch.zeros((cap, width), dtype=torch.float32, device=dev)
-    rec[: local.shape[0]] = torch.from_numpy(np.ascontiguousarray(local)).to(dev)
-    idt = torch.zeros(cap, dtype=torch.int64, device=dev)
-    idt[: len(ids)] = torch.from_numpy(np.ascontiguousarray(ids)).to(dev)
+    n_local, width = local.shape
+    if capacity is None:
+        n = torch.tensor([n_local], dtype=torch.int64, device=dev)
+        sizes = [torch.zeros_like(n) for _ in range(world)]
+        dist.all_gather(sizes, n, group=group)                           # 8 bytes per rank, only when the caller cannot say
+        capacity = max(int(c.item()) for c in sizes)
+    if n_local > capacity:
+        raise ValueError(f"{n_local} local records exceed the stated capacity {capacity}")
+    block = np.zeros((capacity + 1, width + 2), dtype=np.int32)
+    block[0, 0] = n_local
+    block[1:n_local + 1, :width] = np.ascontiguousarray(local).view(np.int32)
+    block[1:n_local + 1, width:] = np.ascontiguousarray(ids).view(np.int32).reshape(-1, 2)     # little endian: low, high
+    send = torch.from_numpy(block).to(dev)
     if all_ranks:
-        rparts = [torch.zeros_like(rec) for _ in range(world)]
-        iparts = [torch.zeros_like(idt) for _ in range(world)]
-        dist.all_gather(rparts, rec, group=group)
-        dist.all_gather(iparts, idt, group=group)
+        parts = [torch.zeros_like(send) for _ in range(world)]
+        dist.all_gather(parts, send, group=group)
     else:
         root = rank == dst
-        rparts = [torch.zeros_like(rec) for _ in range(world)] if root else None
-        iparts = [torch.zeros_like(idt) for _ in range(world)] if root else None
-        dist.gather(rec, rparts, dst=dst, group=group)
-        dist.gather(idt, iparts, dst=dst, group=group)
+        parts = [torch.zeros_like(send) for _ in range(world)] if root else None
+        # torch's gather takes the GLOBAL rank of the destination
+        dist.gather(send, parts, dst=dist.get_global_rank(group, dst) if group is not None else dst, group=group)
         if not root:
             return None, None
-    return (torch.cat([p[:c] for p, c in zip(rparts, counts)]).cpu().numpy(),
-            torch.cat([p[:c] for p, c in zip(iparts, counts)]).cpu().numpy())
+    recs, idl = [], []
+    for p in parts:
+        b = p.cpu().numpy()
+        c = int(b[0, 0])
+        recs.append(np.ascontiguousarray(b[1:c + 1, :width]).view(np.float32))
+        idl.append(np.ascontiguousarray(b[1:c + 1, width:]).view(np.int64).reshape(-1))
+    return np.concatenate(recs).reshape(-1, width), np.concatenate(idl)
 
 
-def broadcast_from_root(t, src: int = 0, group=None):
+def broadcast_from_root(t, src: int = 0, group=None, force_collective: bool = False):
     """Config 5's start-up exchange: the MMSE filter W (P x P complex64, 22.5 MB at P = 1 678) is prepared once
     on ``src`` and broadcast to every rank; after that the ranks never talk until the final gather.  ``t`` is the tensor
     on ``src`` and an equally shaped, equally typed buffer elsewhere; complex tensors travel as their real view (RCCL
-    has no complex type).  Returns ``t``.  No-op without an initialised process group."""
+    has no complex type); ``src`` is a rank of ``group``.  Returns ``t``.  No-op without an initialised process group or in a
+    group of one (unless ``force_collective``: the one-rank RCCL rehearsal)."""
     import torch
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size(group) == 1 and not force_collective):
         return t
     buf = torch.view_as_real(t) if t.is_complex() else t
     if not buf.is_contiguous():
         raise ValueError("broadcast_from_root needs a contiguous tensor")
-    dist.broadcast(buf, src=src, group=group)
+    dist.broadcast(buf, src=dist.get_global_rank(group, src) if group is not None else src, group=group)
     return t
 

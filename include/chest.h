@@ -182,8 +182,9 @@ int chest_pattern_get_pilots(chest_ctx* ctx, int32_t slot, int32_t* pilot_idx_ou
 /* Read a slot's plan back in chest_pattern_set's layout: HOST plan_idx uint16[3][G], plan_w float[3][G]. */
 int chest_pattern_get_plan(chest_ctx* ctx, int32_t slot, uint16_t* plan_idx, float* plan_w);
 int chest_pattern_num_pilots(chest_ctx* ctx, int32_t slot);
-/* Device-side error word set by kernels that met a bad frame descriptor (1) or a pattern without a
- * plan (2); reading it synchronises the device and clears it. HOST out. */
+/* Device-side error word set by kernels that met a bad frame descriptor (1), a pattern without a plan (2), or -- in
+ * chest_patterns_build -- a pattern whose Delaunay flips ran into their round limit (3: its plan may not be the Delaunay
+ * one; never seen with the default limit); reading it synchronises the device and clears it. HOST out. */
 int chest_get_status(chest_ctx* ctx, int32_t* status);
 
 /* Per-kernel timing (measurement aid): after chest_profile_begin(ctx, n) the library records HIP event pairs on the
@@ -205,7 +206,9 @@ int chest_profile_read_kernel(chest_ctx* ctx, int32_t kernel_id, float* ms, int3
 /* Tuning knobs for experiments (tools/ only; the launch path reads nothing from the environment).  Keys:
  *   "frame_rx_group"   rx antennas per LDS slab unit of the frame kernel (0 = chosen from the LDS budget)
  *   "frame_min_waves"  4 = the 128-VGPR instantiation of the 2x2 frame kernel (two resident workgroups per CU instead of three)
- *   "pattern_extra_lds" bytes of unused LDS added to the pattern kernel's allocation (workgroups-per-CU experiments) */
+ *   "pattern_extra_lds" bytes of unused LDS added to the pattern kernel's allocation (workgroups-per-CU experiments)
+ *   "pattern_flip_cap"  flip rounds allowed per stage of chest_patterns_build (0 = the default, 4 * triangles + 64; a low
+ *                       value forces the status-3 path for tests) */
 int chest_tune(chest_ctx* ctx, const char* key, int32_t value);
 
 /* ---- launch group (asynchronous, no allocation) -------------------------------------------- */

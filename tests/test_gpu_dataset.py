@@ -166,3 +166,27 @@ def test_config_sized_batch_properties():
     # different frames differ, same (seed, frame) repeats
     again = eng.run_frames(d[:64], seed=2024, frame_offset=0, outputs=("rx",))
     assert torch.equal(again["rx"], out["rx"][:64]) and not torch.equal(out["rx"][0], out["rx"][1])
+
+
+def test_dropin_estimators_and_native_dataset_share_an_engine_safely():
+    """The shared-pattern dataset path builds its patterns in slots 0.. of the engine the drop-in estimators use; a pattern the
+    estimators cached there before must be re-uploaded, not silently served from a slot that now holds another pattern (and
+    the other way round: a slot the estimators took over goes back to the pool without leaking)."""
+    be = importlib.import_module(PKG + ".baseline_estimators")
+    rs = np.random.RandomState(11)
+    S, nsc = 14, 599
+    pil = np.sort(rs.permutation(S * nsc)[:838])
+    pos, mask = O.pattern_from_indices(pil, S, nsc)
+    x = O.unit_symbols(rs.rand(838))
+    rx = (rs.randn(S, 2, nsc) + 1j * rs.randn(S, 2, nsc)).astype(np.complex64)
+    rx4 = np.repeat(rx.astype(complex)[:, :, None, :], 2, axis=2)
+    want = O.ls_estimate(rx4, x, mask, pos, "linear")
+    ls = be.LSEstimator("linear")
+    scale = np.max(np.abs(want))
+    assert np.max(np.abs(ls.estimate(rx4, x, mask, pos) - want)) / scale < 1e-5
+    gen = dg.ChannelEstimationDataset(CFG)
+    a = gen.generate_dataset_native(12, seed=3, pattern_group=4)          # rebuilds slots 0.. of the same engine in place
+    assert np.max(np.abs(ls.estimate(rx4, x, mask, pos) - want)) / scale < 1e-5
+    b = gen.generate_dataset_native(12, seed=3, pattern_group=4)          # ... and takes the slots back again
+    assert np.array_equal(a["H_ls"], b["H_ls"])
+    assert np.max(np.abs(ls.estimate(rx4, x, mask, pos) - want)) / scale < 1e-5

@@ -27,10 +27,13 @@ def incircle(ax, ay, bx, by, cx, cy, dx, dy):
             + (cdx * cdx + cdy * cdy) * (adx * bdy - bdx * ady))
 
 
-def initial_triangulation(px, py):
+def initial_triangulation(px, py, nsc=None):
     """px, py: int arrays sorted by (px, py).  Returns (tri [n,3] counter-clockwise vertex ids, nbr [n,3] with nbr[t][i] the
-    triangle across the edge opposite vertex i, NONE on the hull)."""
+    triangle across the edge opposite vertex i, NONE on the hull); with ``nsc`` (the grid's column count) also region[n]: the
+    column region 0..3 the device numbers the triangle into (a strip step by the doubled midpoint column of its row edge
+    against the thresholds b * 2 nsc / 4; left pockets 0, right pockets 3)."""
     P = len(px)
+    region = []
     rows = np.unique(px)
     start = {r: int(np.searchsorted(px, r, "left")) for r in rows}
     end = {r: int(np.searchsorted(px, r, "right")) for r in rows}
@@ -50,9 +53,13 @@ def initial_triangulation(px, py):
             # the Delaunay triangulation of the two rows alone: advance the row whose next edge has its midpoint further left
             # (ties: the upper row); exhausted rows cannot advance
             if j >= jb or (i < ia and py[i] + py[i + 1] <= py[j] + py[j + 1]):
+                esum = py[i] + py[i + 1]
                 add(i, i + 1, j); i += 1
             else:
+                esum = py[j] + py[j + 1]
                 add(j, j + 1, i); j += 1
+            if nsc is not None:
+                region.append(sum(1 for b in (1, 2, 3) if esum >= (b * 2 * nsc) >> 2))
     # pockets: monotone chain over the first (left) and last (right) point of every occupied row
     for side in (0, 1):
         chain = [start[r] if side == 0 else end[r] - 1 for r in rows]
@@ -66,6 +73,7 @@ def initial_triangulation(px, py):
                 # Collinear b (o == 0) stays a flat hull vertex.
                 if (o < 0 if side == 0 else o > 0):
                     add(a, b, p)
+                    region.append(0 if side == 0 else 3)
                     stack.pop()
                 else:
                     break
@@ -80,6 +88,8 @@ def initial_triangulation(px, py):
                 nbr[t, i] = t2; nbr[t2, i2] = t
             else:
                 edge_owner[key] = (t, i)
+    if nsc is not None:
+        return tri, nbr, np.asarray(region, dtype=np.int64)
     return tri, nbr
 
 
@@ -140,6 +150,78 @@ def flip_rounds(px, py, tri, nbr, max_rounds=100000):
                     k2 = [q for q in range(3) if tri[Y, q] not in (x, y)][0]
                     nbr[Y, k2] = X
     return rounds, flips
+
+
+def flip_rounds_staged(px, py, tri, nbr, region):
+    """The barrier-free schedule of the device (up to 2 048 triangles): stage 1 -- each of four waves runs flip_rounds'
+    rounds on its own region and flips an edge only if its two triangles and their four outer neighbours are the wave's,
+    marking triangles with an edge it could not decide; stage 2 -- one wave owns everything and finishes from the marked
+    triangles.  Only ACTIVE triangles (changed or claimed in the previous round) test their edges, as on the device.
+    Returns ([rounds of wave 0..3], rounds of stage 2, flips of stage 1, flips of stage 2)."""
+    n = len(tri)
+    marked = np.zeros(n, dtype=bool)
+
+    def run(me, active):
+        def mine(x):
+            return x == NONE or me is None or region[x] == me
+        rounds = flips = 0
+        while True:
+            cand = []
+            claim = np.full(n, 1 << 60, dtype=np.int64)
+            for t in np.nonzero(active)[0]:
+                for i in range(3):
+                    u = nbr[t, i]
+                    if u == NONE:
+                        continue
+                    if not mine(u):
+                        marked[t] = True
+                        continue
+                    if u < t and active[u]:
+                        continue
+                    a, b, c = tri[t, i], tri[t, (i + 1) % 3], tri[t, (i + 2) % 3]
+                    j = [k for k in range(3) if tri[u, k] not in (b, c)][0]
+                    d = tri[u, j]
+                    if incircle(px[a], py[a], px[b], py[b], px[c], py[c], px[d], py[d]) > 0:
+                        if not all(mine(x) for x in (nbr[t, (i + 1) % 3], nbr[t, (i + 2) % 3], nbr[u, (j + 1) % 3], nbr[u, (j + 2) % 3])):
+                            marked[t] = True
+                            continue
+                        key = t * 4 + i
+                        cand.append((key, t, i, u, j))
+                        claim[t] = min(claim[t], key); claim[u] = min(claim[u], key)
+            if not cand:
+                return rounds, flips
+            rounds += 1
+            flipped = np.zeros(n, dtype=bool)
+            partner = np.full(n, NONE, dtype=np.int64)
+            for key, t, i, u, j in cand:
+                if claim[t] != key or claim[u] != key:
+                    continue
+                a, b, c, d = tri[t, i], tri[t, (i + 1) % 3], tri[t, (i + 2) % 3], tri[u, j]
+                n_ab, n_ca = nbr[t, (i + 2) % 3], nbr[t, (i + 1) % 3]
+                n_db, n_cd = nbr[u, (j + 1) % 3], nbr[u, (j + 2) % 3]
+                tri[t] = (a, b, d); nbr[t] = (n_db, u, n_ab)
+                tri[u] = (a, d, c); nbr[u] = (n_cd, n_ca, t)
+                flipped[t] = flipped[u] = True
+                partner[t], partner[u] = u, t
+                flips += 1
+            for X in np.nonzero(flipped)[0]:
+                for k in range(3):
+                    Y = nbr[X, k]
+                    if Y == NONE or Y == partner[X]:
+                        continue
+                    x, y = tri[X, (k + 1) % 3], tri[X, (k + 2) % 3]
+                    if flipped[Y]:
+                        if not (x in tri[Y] and y in tri[Y]):
+                            Y = partner[Y]
+                        nbr[X, k] = Y
+                    else:
+                        k2 = [q for q in range(3) if tri[Y, q] not in (x, y)][0]
+                        nbr[Y, k2] = X
+            active = claim < (1 << 60)
+
+    local = [run(w, region == w) for w in range(4)]
+    r2, f2 = run(None, marked.copy())
+    return [r for r, _ in local], r2, sum(f for _, f in local), f2
 
 
 def is_delaunay(px, py, tri, nbr):

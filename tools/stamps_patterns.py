@@ -30,9 +30,11 @@ def main():
         torch.cuda.synchronize()
         raw = buf.cpu().numpy().reshape(n, 16)
         st = raw[:, :7].astype(np.float64)
-        rounds, cross = raw[:, 7] & 0xFFFFFFFF, raw[:, 7] >> 32
+        rounds, cross, solo = raw[:, 7] & 0xFFFFFFFF, (raw[:, 7] >> 32) & 0xFFFFFF, (raw[:, 7] >> 56) & 0xFF
         print(f"P = {P}: flip phases (cycles per pattern, wave 0): test {raw[:, 8].mean():,.0f}  rewrite {raw[:, 9].mean():,.0f}  relink {raw[:, 10].mean():,.0f}  next active set {raw[:, 11].mean():,.0f}")
         print(f"P = {P}: flip rounds mean {rounds.mean():.1f} max {rounds.max()}; walk: most crossings by one lane of wave 0: mean {cross.mean():.0f} max {cross.max()}")
+        print(f"P = {P}: rounds run by wave 0 alone: mean {solo.mean():.1f}; its test phase per round (cycles): record read {raw[:, 12].sum() / max(1, solo.sum()):,.0f}  "
+              f"neighbours + pilots read {raw[:, 13].sum() / max(1, solo.sum()):,.0f}  opposite pilots + in-circle + claims {raw[:, 14].sum() / max(1, solo.sum()):,.0f}  drain {raw[:, 15].sum() / max(1, solo.sum()):,.0f}")
         print(f"P = {P}: total {st.sum(1).mean():,.0f} cycles per pattern")
         for i, nm in enumerate(NAMES):
             print(f"   {nm:16s} {st[:, i].mean():10,.0f}  {st[:, i].sum() / st.sum():6.1%}")
