@@ -49,8 +49,10 @@ WORKLOADS = {
                                types=("EPA", "EVA", "ETU"), dopplers=(10.0, 50.0, 100.0, 200.0),
                                snrs=(-5.0, 0.0, 5.0, 10.0, 15.0, 20.0, 25.0, 30.0), densities=(0.05, 0.10)),
     # kind "fullcov": simulate -> LS at the pilots -> W h_ls on the f32 MFMA pipe -> interpolation (one pattern, W prepared once)
+    # (2 304 frames per step: B * R = 9 216 right-hand sides = 72 row tiles x 14 column tiles = 1 008 GEMM workgroups for the chip's
+    # 2 x 256 slots -- two nearly full rounds; 2 048 frames gave 896 = 1.75 rounds)
     "cfg5_4x4_2048_fullcov": dict(kind="fullcov", T=4, R=4, N=2048, cp=144, U=1200, ct="ETU", fd=555.6, snr=10.0, dens=0.10,
-                                  frames=2048),
+                                  frames=2304),
 }
 PATTERN_GROUP = 1024           # frames that share one pilot pattern / interpolation plan (--pattern-group 1: one per frame)
 
@@ -407,17 +409,42 @@ def measure_leg(job, args, workload, group, steps, warmup, frames=None, patterns
                 SH.broadcast_from_root(W, 0, force_collective=True)
             else:
                 Wc = W.cpu(); SH.broadcast_from_root(Wc, 0, force_collective=True); W.copy_(Wc)
-        scr = eng.mmse_full_scratch(slots[0], F * R)
+        # The step's three legs -- frame kernel (HBM-write-bound), filter W h on the f32 MFMA pipe, interpolation + T-fold stores
+        # (HBM-write-bound) -- run as a software pipeline over `nch` chunks of the batch on three streams: the MFMA-bound filter of
+        # chunk c beside the HBM-bound kernels of chunks c - 1 / c + 1 (--pipeline-chunks 1: strictly in sequence on one stream).
+        nch = max(1, min(int(args.pipeline_chunks), F))
+        bounds = [(F * c // nch, F * (c + 1) // nch) for c in range(nch)]
+        scr = [eng.mmse_full_scratch(slots[0], (b1 - b0) * R) for b0, b1 in bounds]
         out["H_mmse"] = eng.empty_c64(F, S, R, T, nsc)
-        extra.update(prepare_s=round(t_prep, 3))
+        if nch > 1:
+            sF, sG, sI = (torch.cuda.Stream(device=eng.device) for _ in range(3))
+            d_chunks = [d_first[b0 * E.DESC_DTYPE.itemsize: b1 * E.DESC_DTYPE.itemsize] for b0, b1 in bounds]
+        extra.update(prepare_s=round(t_prep, 3), pipeline_chunks=nch)
 
     def step(i):
         off = (i * world + rank) * F
         if kind == "dataset":
             eng.run_frames(dataset_step(off), seed=seed, frame_offset=off, outputs=names, out=out, check=False)
-        elif kind == "fullcov":
+        elif kind == "fullcov" and nch == 1:
             eng.run_frames(d_first, seed=seed, frame_offset=off, outputs=names, out=out, check=False)
-            eng.mmse_full_apply_pilots(out["h_ls_pilots"], slots[0], W, out=out["H_mmse"], scratch=scr)
+            eng.mmse_full_apply_pilots(out["h_ls_pilots"], slots[0], W, out=out["H_mmse"], scratch=scr[0])
+        elif kind == "fullcov":
+            main = torch.cuda.current_stream()
+            sF.wait_stream(main)                                 # (the previous step has finished with every buffer)
+            for c, (b0, b1) in enumerate(bounds):
+                oc = {k: out[k][b0:b1] for k in names}
+                with torch.cuda.stream(sF):
+                    eng.run_frames(d_chunks[c], seed=seed, frame_offset=off + b0, outputs=names, out=oc, check=False)
+                    e_f = torch.cuda.Event(); e_f.record()
+                with torch.cuda.stream(sG):
+                    sG.wait_event(e_f)
+                    eng.mmse_full_filter_pilots(oc["h_ls_pilots"], slots[0], W, scr[c])
+                    e_g = torch.cuda.Event(); e_g.record()
+                with torch.cuda.stream(sI):
+                    sI.wait_event(e_g)
+                    eng.mmse_full_interp_pilots(b1 - b0, slots[0], scr[c], out["H_mmse"][b0:b1])
+            for st_ in (sF, sG, sI):
+                main.wait_stream(st_)
         else:
             if per_step_patterns:
                 eng.build_patterns(0, npil_frames, seed=2024, pattern_ids=np.arange(off, off + F, dtype=np.uint64), method=pf_method)
@@ -439,7 +466,7 @@ def measure_leg(job, args, workload, group, steps, warmup, frames=None, patterns
         dist.barrier()
     torch.cuda.synchronize()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
-    eng.profile_begin(steps)                 # library-side HIP events around each kernel, on the launch stream
+    eng.profile_begin(steps * (nch if kind == "fullcov" else 1))   # library-side HIP events around each kernel, on the launch stream
     t0 = time.perf_counter()
     for i in range(steps):
         ev[i][0].record()
@@ -498,8 +525,8 @@ def measure_leg(job, args, workload, group, steps, warmup, frames=None, patterns
         if "plan_kernels" in kern:
             cfgd["plan_build_kernel_ms"] = kern["plan_kernels"]
         if kind == "fullcov":
-            gemm_ms = kern.get("cgemm_w_kernel_3m", 0.0)
-            flop = 8.0 * P * P * R * F                               # one right-hand side per (frame, rx): quirk Q9
+            gemm_ms = kern.get("cgemm_w_kernel_3m", 0.0)             # per launch; a step launches it once per pipeline chunk
+            flop = 8.0 * P * P * R * F / nch                         # one right-hand side per (frame, rx): quirk Q9
             ach = flop / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
             step_ms = dt / steps * 1e3
             hbm = bytes_frame * F / (step_ms * 1e-3) / 1e9
@@ -612,6 +639,8 @@ def main():
     ap.add_argument("--placement-tries", type=int, default=1,
                     help="candidate allocations per output tensor group (1 = take the first allocation, the default; "
                          ">1 probes placements with the real kernel and keeps the fastest)")
+    ap.add_argument("--pipeline-chunks", type=int, default=1,
+                    help="cfg5: chunks of the batch pipelined over three streams (frame kernel | MFMA filter | interpolation); 1 = in sequence")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-legs", action="store_true",
                     help="default invocation only: skip the per_frame_patterns leg and the `also` legs of the other workloads")

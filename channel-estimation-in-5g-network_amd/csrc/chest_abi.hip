@@ -430,6 +430,8 @@ int chest_tune(chest_ctx* ctx, const char* key, int32_t value) {
     if (strcmp(key, "frame_min_waves") == 0) { ctx->tune_min_waves = value; return CHEST_OK; }
     if (strcmp(key, "pattern_extra_lds") == 0) { ctx->tune_pattern_extra_lds = value < 0 ? 0 : value; return CHEST_OK; }
     if (strcmp(key, "pattern_flip_cap") == 0) { ctx->tune_pattern_flip_cap = value < 0 ? 0 : value; return CHEST_OK; }
+    if (strcmp(key, "pattern_stop_after") == 0) { ctx->tune_pattern_stop_after = value; return CHEST_OK; }
+    if (strcmp(key, "pattern_solo_at") == 0) { ctx->tune_pattern_solo_at = value < 0 ? 0 : value; return CHEST_OK; }
     set_error("chest_tune: unknown key '%s'", key);
     return CHEST_EINVAL;
 }

@@ -89,6 +89,8 @@ struct chest_ctx {
     int32_t tune_rx_group = 0;            // rx antennas per slab unit of the frame kernel (0 = chosen from the LDS budget)
     int32_t tune_min_waves = 0;           // 4 = the 128-VGPR instantiation of the 2x2 frame kernel (two workgroups per CU), for A/B
     int32_t tune_pattern_extra_lds = 0;   // bytes of unused LDS added to the pattern kernel's allocation (occupancy experiments)
+    int32_t tune_pattern_solo_at = 0;     // active triangles at which the pattern kernel's flips go to one wave (0 = default 192)
+    int32_t tune_pattern_stop_after = 0;  // diagnostic: the pattern kernel leaves after phase k (instruction counts per phase; tools/pmc_pattern_phases.sh)
     int32_t tune_pattern_flip_cap = 0;    // flip rounds per stage of the pattern kernel (0 = default); tests force the status-3 path with it
 };
 

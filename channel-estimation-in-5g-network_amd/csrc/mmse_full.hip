@@ -422,18 +422,25 @@ int chest_mmse_full_apply(chest_ctx* ctx, void* stream, int32_t B, const float* 
     return CHEST_OK;
 }
 
-int chest_mmse_full_apply_pilots(chest_ctx* ctx, void* stream, int32_t B, const float* h_ls_pilots, int32_t h_ls_stride,
-                                 int32_t slot, const float* W, float* h_scratch, float* H_est) {
-    if (!ctx || B < 0 || (B > 0 && (!h_ls_pilots || !W || !h_scratch || !H_est))) {
-        set_error("chest_mmse_full_apply_pilots: bad argument");
-        return CHEST_EINVAL;
-    }
+// The two stages of chest_mmse_full_apply_pilots, separately launchable (a pipeline runs the filter of batch n + 1 on the MFMA
+// pipe beside the HBM-bound interpolation of batch n on another stream).  Scratch layout (chest_mmse_full_apply_scratch_bytes):
+// packed right-hand sides [Mpad][Ppad] | filtered pilot values [M][Ppad] | packed W [Npad][Ppad].
+static int full_pilots_check(chest_ctx* ctx, const char* who, int32_t B, int32_t slot, const void* scratch) {
+    if (!ctx || B < 0 || (B > 0 && !scratch)) { set_error("%s: bad argument", who); return CHEST_EINVAL; }
     if (B == 0) return CHEST_OK;
     if (slot < 0 || slot >= (int)ctx->patterns.size() || ctx->patterns[slot].dev.slot == nullptr ||
         ctx->patterns[slot].dev.plan == nullptr || ctx->patterns[slot].dev.pad != 0) {
         set_error("pattern slot %d is not set, has no plan or carries a compact plan", slot);
         return CHEST_ESTATE;
     }
+    return CHEST_OK;
+}
+
+int chest_mmse_full_filter_pilots(chest_ctx* ctx, void* stream, int32_t B, const float* h_ls_pilots, int32_t h_ls_stride,
+                                  int32_t slot, const float* W, float* h_scratch) {
+    int rc = full_pilots_check(ctx, "chest_mmse_full_filter_pilots", B, slot, h_scratch);
+    if (rc != CHEST_OK || B == 0) return rc;
+    if (!h_ls_pilots || !W) { set_error("chest_mmse_full_filter_pilots: bad argument"); return CHEST_EINVAL; }
     CHEST_GUARD(ctx);
     hipStream_t st = (hipStream_t)stream;
     const auto& f = ctx->fp;
@@ -444,17 +451,35 @@ int chest_mmse_full_apply_pilots(chest_ctx* ctx, void* stream, int32_t B, const 
     float2* h_in = (float2*)h_scratch;
     float2* h_out = h_in + (size_t)Mpad * Ppad;
     float2* w_packed = h_out + (size_t)M * Ppad;
+    // chest_frames_run writes h_ls_pilots with the entries P .. h_ls_stride - 1 zeroed: with the row stride of the GEMM operand and
+    // a whole number of 128-row tiles it IS the packed operand -- no copy
+    const bool h_in_place = h_ls_stride == Ppad && M == Mpad && ((uintptr_t)h_ls_pilots & 15) == 0;
+    const float2* h_op = h_in_place ? (const float2*)h_ls_pilots : h_in;
     const int sp_pack = prof_open(ctx, st, CHEST_K_PACK);
-    hipLaunchKernelGGL(pack_h_kernel, dim3(Mpad), dim3(256), 0, st, M, P, h_ls_stride, Ppad, (const float2*)h_ls_pilots, h_in);
+    if (!h_in_place) hipLaunchKernelGGL(pack_h_kernel, dim3(Mpad), dim3(256), 0, st, M, P, h_ls_stride, Ppad, (const float2*)h_ls_pilots, h_in);
     hipLaunchKernelGGL(pack_w_kernel, dim3(Npad), dim3(256), 0, st, P, Ppad, (const float2*)W, w_packed);
     prof_close(ctx, st, sp_pack);
     CHEST_LDS_OPT_IN(ctx, LDS_GEMM3M, cgemm_w_kernel_3m, T3_LDS_BYTES);
     const int sp_gemm = prof_open(ctx, st, CHEST_K_GEMM);
     hipLaunchKernelGGL(cgemm_w_kernel_3m, dim3(Npad / T2_N, Mpad / T2_M), dim3(256), T3_LDS_BYTES, st, P, Ppad, M, Ppad,
-                       (const float2*)w_packed, h_in, h_out);
+                       (const float2*)w_packed, h_op, h_out);
     prof_close(ctx, st, sp_gemm);
+    CHEST_HIP(hipGetLastError());
+    return CHEST_OK;
+}
+
+int chest_mmse_full_interp_pilots(chest_ctx* ctx, void* stream, int32_t B, int32_t slot, const float* h_scratch, float* H_est) {
+    int rc = full_pilots_check(ctx, "chest_mmse_full_interp_pilots", B, slot, h_scratch);
+    if (rc != CHEST_OK || B == 0) return rc;
+    if (!H_est) { set_error("chest_mmse_full_interp_pilots: bad argument"); return CHEST_EINVAL; }
+    if (((uintptr_t)H_est & 15) != 0) { set_error("chest_mmse_full_interp_pilots: H_est must be 16-byte aligned"); return CHEST_EINVAL; }
+    CHEST_GUARD(ctx);
+    hipStream_t st = (hipStream_t)stream;
+    const auto& f = ctx->fp;
+    const PatternDev& pd = ctx->patterns[slot].dev;
+    const int P = pd.P, Ppad = pad16(P), M = B * f.R;
+    const float2* h_out = (const float2*)h_scratch + (size_t)pad128(M) * Ppad;
     const size_t lds = ((size_t)((P + 1) & ~1) + (size_t)f.nsc) * sizeof(float2);
-    if (((uintptr_t)H_est & 15) != 0) { set_error("chest_mmse_full_apply_pilots: H_est must be 16-byte aligned"); return CHEST_EINVAL; }
     CHEST_LDS_OPT_IN(ctx, LDS_INTERP_TFOLD, interp_from_pilots_tfold_kernel, lds);
     const int sp_int = prof_open(ctx, st, CHEST_K_INTERP);
     hipLaunchKernelGGL(interp_from_pilots_tfold_kernel, dim3(M), dim3(256), lds, st, f.S, f.R, f.T, f.nsc, Ppad, ctx->d_patterns,
@@ -462,6 +487,13 @@ int chest_mmse_full_apply_pilots(chest_ctx* ctx, void* stream, int32_t B, const 
     prof_close(ctx, st, sp_int);
     CHEST_HIP(hipGetLastError());
     return CHEST_OK;
+}
+
+int chest_mmse_full_apply_pilots(chest_ctx* ctx, void* stream, int32_t B, const float* h_ls_pilots, int32_t h_ls_stride,
+                                 int32_t slot, const float* W, float* h_scratch, float* H_est) {
+    if (B > 0 && (!H_est || ((uintptr_t)H_est & 15) != 0)) { set_error("chest_mmse_full_apply_pilots: H_est must be a 16-byte aligned device pointer"); return CHEST_EINVAL; }
+    const int rc = chest_mmse_full_filter_pilots(ctx, stream, B, h_ls_pilots, h_ls_stride, slot, W, h_scratch);
+    return rc != CHEST_OK ? rc : chest_mmse_full_interp_pilots(ctx, stream, B, slot, h_scratch, H_est);
 }
 
 int64_t chest_estimate_dense_scratch_bytes(chest_ctx* ctx, int32_t P, int32_t num_grids) {

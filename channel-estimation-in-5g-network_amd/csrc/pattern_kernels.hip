@@ -54,6 +54,9 @@ struct PatBuildArgs {
     int32_t* nsimp_out;           // optional [count]
     int32_t* status;
     int32_t flip_cap;             // flip rounds allowed per stage (0: 4 * NT + 64, never reached); chest_tune "pattern_flip_cap"
+    int32_t solo_at;              // active triangles at which wave 0 takes the flips over (0: the default)
+    int32_t stop_after;           // diagnostic (chest_tune "pattern_stop_after"): leave after phase k = 1 selection, 2 slot table, 3 strips,
+                                  // 4 pockets, 5 flips (0: run to the end) -- instruction counts per phase from counter differences
 };
 
 struct alignas(16) TriRec { uint16_t h[6]; uint32_t claim; };
@@ -194,8 +197,14 @@ __device__ unsigned long long* g_pat_stamp = nullptr;           // [count][16]: 
 #endif
 
 // COMPACT: method 2 (compact 'linear' plan); a template parameter so that the full-plan kernel carries none of its code
+// Launch bounds: eight 256-thread workgroups per CU, i.e. at most 64 VGPRs and 80 SGPRs (with more SGPRs the hardware admits
+// fewer workgroups than the LDS would, MI355X_MICROARCH.md "Residency"; the scalar spills this costs go to VGPR lanes).  Sparse
+// patterns, whose LDS footprint lets more than five workgroups share a CU, gain 10 % (P = 419: 1.48 -> 1.33 ms per 10 000,
+// P = 83: 1.05 -> 0.90); at P = 838 the LDS holds five either way and the kernel is bound by its vector instructions (r03 PMC:
+// 94 k VALU instructions per pattern, vector ALU 82 % busy) -- a 12-B packed record format that fits a sixth workgroup was
+// built, measured at the same 1.85-1.9 ms and dropped (profiles/r03_pattern_ab_formats.txt).
 template <bool COMPACT>
-__global__ void __launch_bounds__(PB_THREADS)
+__global__ void __launch_bounds__(PB_THREADS, 8)
 pattern_build_kernel(const PatBuildArgs A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const int tid = threadIdx.x, j = blockIdx.x;
@@ -339,6 +348,7 @@ pattern_build_kernel(const PatBuildArgs A) {
     __syncthreads();
 
     PSTAMP(0);                                                   // pilot selection
+    if (A.stop_after == 1) return;
     // ================= 2. slot table ==============================================================================
     // Assembled in LDS (the triangle area is still free) and written out as whole 16-B vectors: a thread's own elements are
     // consecutive, so direct 2-byte stores would touch a different cache line from every lane.
@@ -365,6 +375,7 @@ pattern_build_kernel(const PatBuildArgs A) {
         }
     }
     PSTAMP(1);                                                   // slot table
+    if (A.stop_after == 2) return;
     if (A.method < 0) return;                                    // simulation-only pattern: no plan
 
     // per-row tables
@@ -469,6 +480,7 @@ pattern_build_kernel(const PatBuildArgs A) {
     }
     __syncthreads();
     PSTAMP(3);                                                   // strips
+    if (A.stop_after == 3) return;
     // pockets between the end chains and the convex hull (<= 2 (m - 2) triangles).  A monotone-chain scan over the first (left) /
     // last (right) pilot of every occupied row; every boundary edge of the scan carries its owner (triangle, slot), so each
     // pocket triangle is linked to its neighbours in O(1).  The scan itself is serial, but nothing in it waits for the LDS:
@@ -558,6 +570,7 @@ pattern_build_kernel(const PatBuildArgs A) {
     __syncthreads();
     const int ntri = cnt_s[2];
     PSTAMP(4);                                                   // pockets
+    if (A.stop_after == 4) return;
 
     // ================= 4. Lawson flips ==============================================================================
     // Rounds of independent flips.  A triangle is ACTIVE (its claim word starts the round as CLAIM_DIRTY) if it changed or lost a
@@ -579,7 +592,7 @@ pattern_build_kernel(const PatBuildArgs A) {
     //            and issue nothing (r03 stamps: 8 of 14 rounds; a third of the kernel's instructions).
     // Both stages flip by the same rules, so the triangulation does not depend on where the switch happens.
     constexpr uint32_t CLAIM_NONE = 0xFFFFFFFFu, CLAIM_DIRTY = 0xFFFFFFFEu, CLAIM_WON = 0x40000000u;
-    constexpr int FLIP_SOLO_AT = 192;
+    const int FLIP_SOLO_AT = A.solo_at > 0 ? A.solo_at : 192;      // (chest_tune "pattern_solo_at": experiments)
     const int lane = tid & 63, wave = tid >> 6, wbase = tid & ~63;
     const int round_cap = A.flip_cap > 0 ? A.flip_cap : 4 * NT + 64;
     const bool can_solo = ntri <= 2048 && PB_THREADS == 256;
@@ -792,6 +805,7 @@ pattern_build_kernel(const PatBuildArgs A) {
     __syncthreads();
 
     PSTAMP(5);                                                   // flips
+    if (A.stop_after == 5) return;
     if (A.simp_out != nullptr) {
         int32_t* so = A.simp_out + (size_t)j * 2 * A.Pcap * 3;
         for (int t = tid; t < ntri; t += PB_THREADS) { so[3 * t] = TR[t].h[0]; so[3 * t + 1] = TR[t].h[1]; so[3 * t + 2] = TR[t].h[2]; }
@@ -1052,7 +1066,7 @@ extern "C" int chest_patterns_build(chest_ctx* ctx, void* stream, int32_t first_
     a.num_pilots = d_np; a.given_idx = pilot_idx; a.pattern_ids = d_ids; a.seed = seed; a.idx_stride = idx_stride;
     a.first_slot = first_slot; a.S = ctx->fp.S; a.nsc = ctx->fp.nsc; a.method = method; a.Pcap = pool->Pcap;
     a.simp_out = simplices_out; a.nbr_out = simplices_out ? neighbors_out : nullptr; a.nsimp_out = num_simplices_out; a.status = ctx->d_status;
-    a.flip_cap = ctx->tune_pattern_flip_cap;
+    a.flip_cap = ctx->tune_pattern_flip_cap; a.stop_after = ctx->tune_pattern_stop_after; a.solo_at = ctx->tune_pattern_solo_at;
     if (simplices_out && pool->Pcap != Pmax) { set_error("chest_patterns_build: simplices_out needs a fresh slot range (row stride is 2*Pmax*3)"); return CHEST_EINVAL; }
     const size_t lds_run = pattern_build_lds_bytes(G, pool->Pcap) + (size_t)ctx->tune_pattern_extra_lds;
     const int sp = prof_open(ctx, st, CHEST_K_PLAN);

@@ -552,6 +552,34 @@ class Engine:
             torch.cuda.current_stream(self.device).synchronize()   # our scratch is freed on return
         return out
 
+    def mmse_full_filter_pilots(self, h_ls_pilots, slot, W, scratch):
+        """Stage 1 of ``mmse_full_apply_pilots`` on the current stream: W h_ls for every (frame, rx) on the MFMA pipe; the
+        filtered pilot values stay in ``scratch`` (``mmse_full_scratch(slot, B * R)``, one per batch in flight)."""
+        g = self.geom
+        h = self._c64(h_ls_pilots)
+        P = self.num_pilots(slot)
+        if h.dim() != 3 or h.shape[1] != g.num_rx or h.shape[2] < P or not h.is_contiguous():
+            raise ValueError(f"h_ls_pilots must be a contiguous [B, {g.num_rx}, >= {P}] tensor")
+        if tuple(W.shape) != (P, P) or not W.is_contiguous():
+            raise ValueError(f"W must be a contiguous [{P}, {P}] tensor for this pattern")
+        B = h.shape[0]
+        need = N.lib().chest_mmse_full_apply_scratch_bytes(P, B * g.num_rx)
+        if scratch.numel() * scratch.element_size() < need:
+            raise ValueError(f"scratch holds {scratch.numel() * scratch.element_size()} B, {need} B needed")
+        N.check(N.lib().chest_mmse_full_filter_pilots(self._h, self._stream(), B, h.data_ptr(), h.shape[2], int(slot), W.data_ptr(),
+                                                      scratch.data_ptr()), "chest_mmse_full_filter_pilots")
+
+    def mmse_full_interp_pilots(self, num_frames, slot, scratch, out):
+        """Stage 2 on the current stream: interpolation of the filtered pilot values in ``scratch`` + T-fold stores into
+        ``out`` [B, S, R, T, nsc] (contiguous complex64)."""
+        g = self.geom
+        shape = (int(num_frames), g.num_symbols, g.num_rx, g.num_tx, g.num_sc)
+        if tuple(out.shape) != shape or out.dtype != torch.complex64 or not out.is_contiguous():
+            raise ValueError("out must be a contiguous complex64 [B,S,R,T,nsc] tensor")
+        N.check(N.lib().chest_mmse_full_interp_pilots(self._h, self._stream(), int(num_frames), int(slot), scratch.data_ptr(),
+                                                      out.data_ptr()), "chest_mmse_full_interp_pilots")
+        return out
+
     def mmse_full_scratch(self, slot, num_grids):
         """Reusable scratch tensor for mmse_full_apply(_pilots) on ``num_grids`` right-hand sides of this pattern."""
         return torch.empty(N.lib().chest_mmse_full_apply_scratch_bytes(self.num_pilots(slot), int(num_grids)), dtype=torch.uint8,

@@ -207,6 +207,8 @@ int chest_profile_read_kernel(chest_ctx* ctx, int32_t kernel_id, float* ms, int3
  *   "frame_rx_group"   rx antennas per LDS slab unit of the frame kernel (0 = chosen from the LDS budget)
  *   "frame_min_waves"  4 = the 128-VGPR instantiation of the 2x2 frame kernel (two resident workgroups per CU instead of three)
  *   "pattern_extra_lds" bytes of unused LDS added to the pattern kernel's allocation (workgroups-per-CU experiments)
+ *   "pattern_solo_at"   workgroup-wide active triangles at which one wave takes over the Delaunay flips (0 = default)
+ *   "pattern_stop_after" diagnostic: chest_patterns_build's kernel leaves after phase k = 1..5 (tools/pmc_pattern_phases.sh)
  *   "pattern_flip_cap"  flip rounds allowed per stage of chest_patterns_build (0 = the default, 4 * triangles + 64; a low
  *                       value forces the status-3 path for tests) */
 int chest_tune(chest_ctx* ctx, const char* key, int32_t value);
@@ -320,6 +322,14 @@ int chest_mmse_full_apply(chest_ctx* ctx, void* stream, int32_t num_frames, cons
  * scratch: chest_mmse_full_apply_scratch_bytes(P, B*R) bytes. */
 int chest_mmse_full_apply_pilots(chest_ctx* ctx, void* stream, int32_t num_frames, const float* h_ls_pilots,
                                  int32_t h_ls_stride, int32_t pattern_slot, const float* W, float* h_scratch, float* H_est);
+/* Its two stages on their own -- filter: pack + W h_ls on the MFMA pipe, the filtered pilot values stay in h_scratch; interp:
+ * interpolation of those values + the T-fold stores -- so that a caller can pipeline batches: the (MFMA-bound) filter of batch
+ * n + 1 on one stream beside the (HBM-bound) interpolation of batch n on another.  One h_scratch per batch in flight.
+ * apply_pilots(...) == filter_pilots(...) followed by interp_pilots(...) on the same stream. */
+int chest_mmse_full_filter_pilots(chest_ctx* ctx, void* stream, int32_t num_frames, const float* h_ls_pilots,
+                                  int32_t h_ls_stride, int32_t pattern_slot, const float* W, float* h_scratch);
+int chest_mmse_full_interp_pilots(chest_ctx* ctx, void* stream, int32_t num_frames, int32_t pattern_slot,
+                                  const float* h_scratch, float* H_est);
 
 /* Dense Clough-Tocher ('cubic') operator of a pattern, built ON THE DEVICE from a triangulation (griddata(method='cubic') =
  * scipy.interpolate.CloughTocher2DInterpolator, reached through src/baseline_estimators.py:65-79): global gradient
