@@ -584,10 +584,32 @@ EXTRA_LEGS = (("cfg1_siso_epa_ls", PATTERN_GROUP), ("cfg3_4x4_etu_mmse", PATTERN
               ("cfg5_4x4_2048_fullcov", PATTERN_GROUP))
 
 
+class _QuietStdout:
+    """The contract is ONE JSON line on stdout, but libraries below us write there too (RCCL prints a five-line version banner
+    from C when the first communicator comes up; gloo chats as well).  While the job runs, file descriptor 1 points at
+    stderr; `restore()` flushes the C library's buffers first -- or the banner would surface at exit, after our line -- and puts
+    stdout back for the result."""
+    def __init__(self):
+        sys.stdout.flush()
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def restore(self):
+        import ctypes
+        sys.stdout.flush()
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+
+
 def run(args):
     import torch
     if args.selftest_spawn:
         return _selftest_spawn(int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")))
+    quiet = _QuietStdout()
     job = Job(args)
     res = measure_leg(job, args, args.workload, args.pattern_group, args.steps, args.warmup, frames=args.frames,
                       patterns_resident=args.patterns_resident, cpu=job.world == 1 and not args.no_cpu_baseline)
@@ -614,9 +636,10 @@ def run(args):
                 also[name] = _brief(leg)
         if job.rank == 0:
             res["also"] = also
+    job.close()
+    quiet.restore()
     if job.rank == 0:
         print(json.dumps(res), flush=True)
-    job.close()
 
 
 def main():

@@ -42,6 +42,7 @@ def test_bench_rehearses_its_collectives_through_one_rank_rccl(workload, frames)
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--rccl-rehearsal", "--workload", workload, "--frames", str(frames),
                         "--steps", "2", "--warmup", "1", "--no-cpu-baseline"], env=_env(), capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stderr[-3000:]
+    assert len(p.stdout.strip().splitlines()) == 1, p.stdout[:2000]      # RCCL's version banner and the like must not reach stdout
     rec = _json_line(p.stdout)
     assert rec["n_gpus"] == 1 and rec["config"]["collectives"] == "executed (nccl, world 1)"
     assert rec["value"] > 0 and rec["est_mse"]["mmse"] > 0

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Copy what tools/collect_profiles.sh left under gpurun_out/r02/ into profiles/r02_* (the tracked, judged copies) and derive
-profiles/pmc_traffic.json from the two PMC passes:  python tools/assemble_profiles.py [--round r02]"""
+"""Copy what tools/collect_profiles.sh left under gpurun_out/<round>/ into profiles/<round>_* (the tracked, judged copies) and derive
+profiles/pmc_traffic.json from the two PMC passes:  python tools/assemble_profiles.py [--round r03]"""
 import argparse
 import csv
 import glob
@@ -38,11 +38,14 @@ def chest_rows(src, dst, keep=("chest::",)):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--round", default="r02")
+    ap.add_argument("--round", default="r03")
     a = ap.parse_args()
     R = a.round
     src, dst = os.path.join(ROOT, "gpurun_out", R), os.path.join(ROOT, "profiles")
-    plain = ["bench_cfg1.json", "bench_cfg2.json", "bench_cfg3.json", "bench_cfg4.json", "bench_cfg5.json", "bench_cfg2_pattern_per_frame.json",
+    plain = ["bench_default.json", "bench_cfg2_rccl_one_rank.json", "pmc_pattern_phases_P838.txt", "pmc_pattern_phases_P83.txt", "pmc_sq_pattern_kernel.txt",
+             "footprint_sweep.txt", "bench_cfg4_pf_125000.json", "bench_cfg4_pf_10000.json", "bench_cfg4_shared_125000.json", "bench_cfg5_12500.json",
+             "bench_cfg5_chunks1.json", "bench_cfg5_chunks2.json", "bench_cfg5_chunks4.json", "bench_cfg5_chunks8.json",
+             "bench_cfg1.json", "bench_cfg2.json", "bench_cfg3.json", "bench_cfg4.json", "bench_cfg5.json", "bench_cfg2_pattern_per_frame.json",
              "bench_cfg2_pattern_per_frame_resident.json", "bench_cfg4_pattern_per_frame.json", "bench_cfg2_gloo2_one_gpu.json",
              "ab_paths_cfg1.txt", "ab_paths_cfg2.txt", "ab_paths_cfg3.txt", "ablate_outputs.txt", "stamps_frame_kernel.txt",
              "stamps_pattern_kernel.txt", "bench_patterns.txt", "bench_prepare.txt", "dropin_latency.txt", "bench_cubic.txt",
@@ -51,7 +54,7 @@ def main():
         p = os.path.join(src, f)
         if os.path.exists(p):
             shutil.copy(p, os.path.join(dst, f"{R}_{f}"))
-    for tag in ("cfg2", "cfg5", "cfg4pf"):
+    for tag in ("cfg2", "cfg2pf", "cfg5", "cfg4pf"):
         st = newest(os.path.join(src, f"prof_{tag}", "**", "*_kernel_stats.csv"))
         if st:
             shutil.copy(st, os.path.join(dst, f"{R}_{tag}_kernel_stats.csv"))
