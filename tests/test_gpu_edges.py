@@ -219,6 +219,40 @@ def test_full_covariance_mmse_at_baseline_sizes(N, cp, U, T, R, B):
                 assert relerr(got[b, :, r, t, :], want) < TOL
 
 
+def test_full_covariance_stages_and_in_place_gemm_operand():
+    """chest_mmse_full_apply_pilots = filter (MFMA) + interp (HBM-bound), separately launchable for pipelines; and when the frame
+    kernel's h_ls_pilots already has the GEMM operand's layout (row stride = padded pilot count, B * R a multiple of the 128-row
+    tile) it is read in place instead of being packed.  Config-5 geometry: stride 1 680 = pad16(1 678); 32 frames x 4 rx = 128
+    rows take the in-place route, 33 frames the packed one -- same bits for the frames they share."""
+    geom = E.Geometry(fft_size=2048, cp_length=144, useful_subcarriers=1200, num_tx=4, num_rx=4)
+    eng = E.get_engine(geom, 0)
+    S, nsc, G = geom.num_symbols, geom.num_sc, geom.grid
+    P = int(G * 0.1)
+    pil = np.sort(np.random.RandomState(21).permutation(G)[:P])
+    slot = eng.pattern_slot(pil, "linear")
+    W = eng.mmse_full_prepare(_config5_covariance(2048, 144, 1200, 4, "ETU", 555.6, pil), 10.0)
+    sim = eng.run_frames(E.make_descs("ETU", 555.6, 10.0, slot, n=33), seed=4, outputs=("h_ls_pilots",))
+    hls = sim["h_ls_pilots"]
+    assert hls.shape == (33, 4, 1680)
+    packed = eng.mmse_full_apply_pilots(hls, slot, W)                      # 132 rows: packed operand
+    h32 = hls[:32].contiguous()
+    in_place = eng.mmse_full_apply_pilots(h32, slot, W)                    # 128 rows, stride == Ppad: read in place
+    assert torch.equal(in_place, packed[:32])
+    scr = eng.mmse_full_scratch(slot, 32 * 4)
+    out = eng.empty_c64(32, S, 4, 4, nsc)
+    side = torch.cuda.Stream(device=eng.device)
+    eng.mmse_full_filter_pilots(h32, slot, W, scr)
+    ev = torch.cuda.Event(); ev.record()
+    with torch.cuda.stream(side):                                          # the second stage on another stream, behind an event
+        side.wait_event(ev)
+        eng.mmse_full_interp_pilots(32, slot, scr, out)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    assert torch.equal(out, in_place)
+    with pytest.raises(ValueError):
+        eng.mmse_full_interp_pilots(31, slot, scr, out)                    # out does not match the frame count
+
+
 @pytest.mark.parametrize("P", [3, 63, 64, 65, 130, 200])
 def test_full_covariance_prepare_at_block_boundaries(P):
     """Blocked Gauss-Jordan with 64-wide pivot blocks: fewer pilots than one block, exactly one, one more (identity padding),
