@@ -620,20 +620,32 @@ def run(args):
     default_run = (args.workload == "cfg2_2x2_eva_ls_mmse" and args.pattern_group == PATTERN_GROUP and args.frames is None
                    and args.patterns == "device" and not args.no_extra_legs and job.world == 1)
     if default_run:
-        pf = measure_leg(job, args, args.workload, 1, max(5, min(args.steps, 10)), 2)
+        # (a failing extra leg must not cost the driver its main line: its error is reported in place of its record)
+        def leg(*a, **k):
+            try:
+                return measure_leg(job, args, *a, **k), None
+            except Exception as e:                                       # noqa: BLE001 -- reported, not swallowed
+                import traceback
+                traceback.print_exc(file=sys.stderr)
+                torch.cuda.empty_cache()
+                return None, f"{type(e).__name__}: {e}"
+        pf, err = leg(args.workload, 1, max(5, min(args.steps, 10)), 2)
         if job.rank == 0:
-            r = pf["roofline"]
-            res["per_frame_patterns"] = {
-                "value": pf["value"], "ms_per_step": pf["ms_per_step"], "frac": r["step_frac"],
-                "pattern_kernel_ms": pf["config"].get("plan_build_kernel_ms"), "frame_kernel_ms": r["kernel_ms"],
-                "taps_kernel_ms": r["taps_kernel_ms"], "frame_kernel_frac": r["frac"], "bytes_per_frame": r["bytes_per_frame"],
-                "plan_format": pf["config"].get("plan_format"), "steps": pf["steps"],
-                "note": "frac = bytes_per_frame x frames/s / 8 TB/s over the WHOLE step (pattern kernel + taps + frame kernel)"}
+            if pf is None:
+                res["per_frame_patterns"] = {"error": err}
+            else:
+                r = pf["roofline"]
+                res["per_frame_patterns"] = {
+                    "value": pf["value"], "ms_per_step": pf["ms_per_step"], "frac": r["step_frac"],
+                    "pattern_kernel_ms": pf["config"].get("plan_build_kernel_ms"), "frame_kernel_ms": r["kernel_ms"],
+                    "taps_kernel_ms": r["taps_kernel_ms"], "frame_kernel_frac": r["frac"], "bytes_per_frame": r["bytes_per_frame"],
+                    "plan_format": pf["config"].get("plan_format"), "steps": pf["steps"],
+                    "note": "frac = bytes_per_frame x frames/s / 8 TB/s over the WHOLE step (pattern kernel + taps + frame kernel)"}
         also = {}
         for name, grp in EXTRA_LEGS:
-            leg = measure_leg(job, args, name, grp, 5, 2)
+            rec, err = leg(name, grp, 5, 2)
             if job.rank == 0:
-                also[name] = _brief(leg)
+                also[name] = _brief(rec) if rec is not None else {"error": err}
         if job.rank == 0:
             res["also"] = also
     job.close()
