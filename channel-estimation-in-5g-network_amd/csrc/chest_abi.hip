@@ -428,6 +428,7 @@ int chest_tune(chest_ctx* ctx, const char* key, int32_t value) {
     if (!ctx || !key) { set_error("chest_tune: null argument"); return CHEST_EINVAL; }
     if (strcmp(key, "frame_rx_group") == 0) { ctx->tune_rx_group = value; return CHEST_OK; }
     if (strcmp(key, "frame_min_waves") == 0) { ctx->tune_min_waves = value; return CHEST_OK; }
+    if (strcmp(key, "taps_threads") == 0) { ctx->tune_taps_threads = (value == 64 || value == 128 || value == 256) ? value : 0; return CHEST_OK; }
     if (strcmp(key, "pattern_extra_lds") == 0) { ctx->tune_pattern_extra_lds = value < 0 ? 0 : value; return CHEST_OK; }
     if (strcmp(key, "pattern_flip_cap") == 0) { ctx->tune_pattern_flip_cap = value < 0 ? 0 : value; return CHEST_OK; }
     if (strcmp(key, "pattern_stop_after") == 0) { ctx->tune_pattern_stop_after = value; return CHEST_OK; }

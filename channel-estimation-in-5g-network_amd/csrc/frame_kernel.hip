@@ -196,8 +196,12 @@ int launch_frames(chest_ctx* ctx, hipStream_t st, int32_t B, const chest_frame_d
         return CHEST_EINVAL;
     }
     // optional per-kernel timing (chest_profile_begin): events on the launch stream around each of the two kernels
+    // workgroup size by the work a frame holds (T * R links x taps x 20 oscillators, 14 x T * R x taps gains): a SISO frame gives a
+    // 256-thread workgroup a fraction of one pass -- one wave per frame: 0.041 against 0.051 ms per 10 000 frames; 2x2: 64 / 128 / 256
+    // threads 0.110 / 0.087 / 0.087 ms, 4x4: 0.415 / 0.289 / 0.208 (tools/ab_taps_threads.py; chest_tune "taps_threads")
+    const int taps_threads = ctx->tune_taps_threads > 0 ? ctx->tune_taps_threads : (fp.T * fp.R <= 1 ? 64 : 256);
     const int sp1 = prof_open(ctx, st, CHEST_K_TAPS);
-    hipLaunchKernelGGL(taps_kernel, dim3(B), dim3(256), lds1, st, ctx->d_fp, descs, (int)ctx->patterns.size(), ctx->d_gram, seed,
+    hipLaunchKernelGGL(taps_kernel, dim3(B), dim3(taps_threads), lds1, st, ctx->d_fp, descs, (int)ctx->patterns.size(), ctx->d_gram, seed,
                        frame_offset, inj_v.u_angle, inj_v.u_phase, inj_v.inj_paths, (float*)workspace, ctx->d_status, out->frame_status);
     prof_close(ctx, st, sp1);
     const int sp2 = prof_open(ctx, st, CHEST_K_FRAME);

@@ -206,6 +206,7 @@ int chest_profile_read_kernel(chest_ctx* ctx, int32_t kernel_id, float* ms, int3
 /* Tuning knobs for experiments (tools/ only; the launch path reads nothing from the environment).  Keys:
  *   "frame_rx_group"   rx antennas per LDS slab unit of the frame kernel (0 = chosen from the LDS budget)
  *   "frame_min_waves"  4 = the 128-VGPR instantiation of the 2x2 frame kernel (two resident workgroups per CU instead of three)
+ *   "taps_threads"     workgroup size of the taps kernel: 64, 128 or 256 (0 = chosen from the antenna count)
  *   "pattern_extra_lds" bytes of unused LDS added to the pattern kernel's allocation (workgroups-per-CU experiments)
  *   "pattern_solo_at"   workgroup-wide active triangles at which one wave takes over the Delaunay flips (0 = default)
  *   "pattern_stop_after" diagnostic: chest_patterns_build's kernel leaves after phase k = 1..5 (tools/pmc_pattern_phases.sh)
