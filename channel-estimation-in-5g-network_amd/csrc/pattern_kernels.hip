@@ -592,6 +592,7 @@ pattern_build_kernel(const PatBuildArgs A) {
     //            and issue nothing (r03 stamps: 8 of 14 rounds; a third of the kernel's instructions).
     // Both stages flip by the same rules, so the triangulation does not depend on where the switch happens.
     constexpr uint32_t CLAIM_NONE = 0xFFFFFFFFu, CLAIM_DIRTY = 0xFFFFFFFEu, CLAIM_WON = 0x40000000u;
+    constexpr uint32_t CLAIM_KEEP = 0xFFFFFFFDu;                 // unclaimed but kept active (first round); any real key is smaller
     const int FLIP_SOLO_AT = A.solo_at > 0 ? A.solo_at : 192;      // (chest_tune "pattern_solo_at": experiments)
     const int lane = tid & 63, wave = tid >> 6, wbase = tid & ~63;
     const int round_cap = A.flip_cap > 0 ? A.flip_cap : 4 * NT + 64;
@@ -651,6 +652,39 @@ pattern_build_kernel(const PatBuildArgs A) {
 #ifdef CHEST_STAMPS
             if (solo) { ++dbg_solo_rounds; dbg_u = __builtin_amdgcn_s_memtime(); }
 #endif
+            // The FIRST round knows more than the later ones: every strip is the Delaunay triangulation of its two rows, so the
+            // only edges that can fail are the ROW edges (shared by the strips above and below a row) -- one in-circle test per
+            // strip triangle instead of three (r03 PMC: the first round was 9.9 k of the flips' 53.7 k vector instructions).  Pocket
+            // triangles and the strip triangles next to them carry unchecked edges: they take no test here and stay active
+            // (CLAIM_KEEP: unclaimed, but alive for the next round, which tests all their edges).
+            if (round == 0 && !solo) {
+                wave_balanced(active, lane, [&](int owner, int bit) {
+                    const uint32_t t = (uint32_t)(ibase + owner + istride * bit);
+                    const TriU T0 = ld_tri(TR, t);
+                    const bool pocketish = t >= (uint32_t)nstrip || (T0.n[0] != TNONE && T0.n[0] >= (uint32_t)nstrip) ||
+                                           (T0.n[1] != TNONE && T0.n[1] >= (uint32_t)nstrip) || (T0.n[2] != TNONE && T0.n[2] >= (uint32_t)nstrip);
+                    const uint32_t p0 = pts[T0.v[0]], p1 = pts[T0.v[1]], p2 = pts[T0.v[2]];
+                    // A-step (p, apex, p + 1): the row edge lies opposite vertex 1; B-step (p, p + 1, apex): opposite vertex 2
+                    const bool a_step = px_of(p0) == px_of(p2);
+                    const uint32_t u = a_step ? T0.n[1] : T0.n[2];
+                    const bool need = !pocketish && u != TNONE && t < u;                 // (both sides are active: the smaller one tests)
+                    const TriU U0 = ld_tri(TR, need ? u : t);
+                    const uint32_t b = a_step ? T0.v[2] : T0.v[0], c = a_step ? T0.v[0] : T0.v[1];   // the edge (b, c), counter-clockwise after the apex
+                    const uint32_t d = (U0.v[0] != b && U0.v[0] != c) ? U0.v[0] : ((U0.v[1] != b && U0.v[1] != c) ? U0.v[1] : U0.v[2]);
+                    const uint32_t pd = pts[need ? d : T0.v[0]];
+                    const uint32_t pa = a_step ? p1 : p2, pb = a_step ? p2 : p0, pc = a_step ? p0 : p1;
+                    bool mark = pocketish;
+                    if (pocketish) atomicMin(&TR[t].claim, CLAIM_KEEP);
+                    if (need && incircle(pa, pb, pc, pd) > 0) {
+                        const uint32_t key = t * 4u + (a_step ? 1u : 2u);
+                        atomicMin(&TR[t].claim, key);
+                        atomicMin(&TR[u].claim, key);
+                        atomicOr(&pmask[ibase + owner], 1u << bit);
+                        mark = true;
+                    }
+                    if (mark) cnt_s[3] = 1;
+                });
+            } else
             wave_balanced(active, lane, [&](int owner, int bit) {
                 const uint32_t t = (uint32_t)(ibase + owner + istride * bit);
                 const TriU T0 = ld_tri(TR, t);
