@@ -274,8 +274,8 @@ def test_delaunay_cpu_model_of_the_device_triangulator_is_valid():
         assert M.is_delaunay(px, py, tri, nbr)
         assert len(tri) == len(Delaunay(np.column_stack([px, py])).simplices)
         assert rounds < 40 and flips < 4 * P
-        # the device's barrier-free schedule (four column regions flipped independently, then one global pass from the marked
-        # triangles) reaches a valid Delaunay triangulation too
+        # a region-local schedule (four column regions flipped independently, then one global pass from the marked triangles:
+        # built on the device in round 3, dropped for its extra rounds) reaches a valid Delaunay triangulation too
         tri2, nbr2, region = M.initial_triangulation(px, py, nsc=nsc)
         local_rounds, global_rounds, f1, f2 = M.flip_rounds_staged(px, py, tri2, nbr2, region)
         assert M.is_delaunay(px, py, tri2, nbr2) and len(tri2) == len(tri)

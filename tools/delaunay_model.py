@@ -153,10 +153,13 @@ def flip_rounds(px, py, tri, nbr, max_rounds=100000):
 
 
 def flip_rounds_staged(px, py, tri, nbr, region):
-    """The barrier-free schedule of the device (up to 2 048 triangles): stage 1 -- each of four waves runs flip_rounds'
-    rounds on its own region and flips an edge only if its two triangles and their four outer neighbours are the wave's,
-    marking triangles with an edge it could not decide; stage 2 -- one wave owns everything and finishes from the marked
-    triangles.  Only ACTIVE triangles (changed or claimed in the previous round) test their edges, as on the device.
+    """Model of a schedule that was built on the device in round 3 and DROPPED ("region-local flips"): stage 1 -- each
+    of four waves runs flip_rounds' rounds on its own column region and flips an edge only if its two triangles and their four outer
+    neighbours are the wave's, marking triangles with an edge it could not decide; stage 2 -- one wave owns everything and finishes
+    from the marked triangles.  It reaches a valid Delaunay triangulation (tested), but the cascades blocked at the region boundaries
+    restart in stage 2: about as many rounds again.  (What the device runs -- all waves while the active set is large, one wave for
+    the tail, same rules throughout -- gives exactly flip_rounds' triangulation.)  Only ACTIVE triangles (changed or claimed in the
+    previous round) test their edges, as on the device.
     Returns ([rounds of wave 0..3], rounds of stage 2, flips of stage 1, flips of stage 2)."""
     n = len(tri)
     marked = np.zeros(n, dtype=bool)
