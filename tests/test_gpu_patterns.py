@@ -373,3 +373,50 @@ def test_flip_round_limit_raises_a_pattern_status():
         eng.tune("pattern_flip_cap", 0)
         eng.build_patterns(0, [P] * 3, seed=1, pattern_ids=np.arange(3, dtype=np.uint64), method="linear")
         eng.check_status()
+
+
+@pytest.mark.parametrize("U", [72, 600])
+def test_structured_and_tiny_patterns_triangulate_validly(U):
+    """Patterns a uniform draw never produces: one or two occupied rows, a regular lattice (every adjacent triangle pair
+    co-circular), a sheared lattice on every other row, one pilot per row (every strip empty: the pocket scan's shared chain
+    edges), the two outer columns only, a cluster, a single triangle, three collinear pilots, and tiny random sets -- the
+    device triangulation must be a valid Delaunay triangulation with Qhull's triangle count and hull (tools/stress_patterns.py
+    runs the same checks on a few hundred patterns)."""
+    geom = E.Geometry(useful_subcarriers=U)
+    eng = E.Engine(geom, 0)
+    S, nsc, G = geom.num_symbols, geom.num_sc, geom.grid
+    rs = np.random.RandomState(99 + U)
+    c, w = nsc // 2, min(20, nsc // 4)
+    pats = [np.arange(0, nsc, 7),
+            np.concatenate([np.arange(3, nsc, 11), (S - 1) * nsc + np.arange(0, nsc, 5)]),
+            np.asarray([s * nsc + k for s in range(S) for k in range(0, nsc, 5)]),
+            np.asarray([s * nsc + k for s in range(0, S, 2) for k in range(s % 4, nsc, 4)]),
+            np.asarray([s * nsc + (17 * s) % nsc for s in range(S)]),
+            np.asarray([s * nsc + k for s in range(S) for k in (0, nsc - 1)]),
+            np.unique(np.asarray([rs.randint(S) * nsc + c + rs.randint(-w, w + 1) for _ in range(200)])),
+            np.asarray([0, nsc - 1, (S - 1) * nsc + nsc // 2]),
+            np.asarray([5, 6, 7])]
+    pats += [rs.permutation(G)[:P] for P in (3, 4, 5, 7, 10, 14, 20) for _ in range(3)]
+    pats = [np.sort(np.unique(p)).astype(np.int32) for p in pats]
+    for lo in range(0, len(pats), 8):
+        chunk = pats[lo:lo + 8]
+        idx = np.zeros((len(chunk), max(len(p) for p in chunk)), np.int32)
+        for j, p in enumerate(chunk):
+            idx[j, :len(p)] = p
+        slots, simp, cnt = eng.build_patterns(lo, [len(p) for p in chunk], pilot_idx=idx, method="linear", return_simplices=True)
+        eng.check_status()
+        simp, cnt = simp.cpu().numpy(), cnt.cpu().numpy()
+        for j, p in enumerate(chunk):
+            p64 = p.astype(np.int64)
+            px, py = _coords(p64, nsc)
+            if np.all(_orient(px[0], py[0], px[1], py[1], px, py) == 0):           # collinear: no triangle, everything outside
+                assert cnt[j] == 0
+                A, _, _ = _plan_matrix(eng, int(slots[j]), len(p))
+                assert not A.any()
+                continue
+            tri = simp[j, :cnt[j]].astype(np.int64)
+            _check_triangulation(p64, nsc, tri)
+            ref, sx = _scipy_plan(p64, S, nsc)
+            assert cnt[j] == len(ref.simplices)
+            A, pi, pw = _plan_matrix(eng, int(slots[j]), len(p))
+            assert np.array_equal(A.sum(1) > 0.5, sx >= 0), "hull membership differs"
