@@ -13,6 +13,12 @@ collective); one RCCL gather of the per-rank metric sums closes the job (cfg5 ad
 W once, before the timed region).  Rank 0 prints ONE JSON line.  Inputs (frame descriptors, pilot patterns, interpolation
 plans) are resident in HBM before the timed region; outputs are written to HBM and stay there.
 
+The default invocation (one GPU, config 2) also reports, in the same line and measured after the main timed region,
+`per_frame_patterns` -- the same workload with a new pilot pattern drawn, triangulated and planned on the device for EVERY frame
+inside every timed step, as the reference does (src/channel_simulator.py:390-391, src/baseline_estimators.py:65-79) -- and `also`:
+five steps each of the cfg1 / cfg3 / cfg4 / cfg5 workloads.  `roofline.frac` is the dominant kernel alone, `roofline.step_frac` the
+same bytes over the whole step.
+
 `--gpus N` with N > 1 and no launcher (WORLD_SIZE unset) starts the N ranks itself, one child process per GPU, BEFORE
 this process touches the GPU; under `python -m torch.distributed.run` the launcher's environment is used as is.
 """
