@@ -45,8 +45,10 @@ WORKLOADS = {
     # kind "frames": one chest_frames_run per step, identical parameters for every frame
     "cfg2_2x2_eva_ls_mmse": dict(kind="frames", T=2, R=2, N=1024, cp=72, U=600, ct="EVA", fd=111.1, snr=10.0, dens=0.10,
                                  frames=10000),
+    # BASELINE configs[2] as specified (test_phase2_snr_sweep.py:18-64 of the reference at 4x4): a step = the whole sweep, eight
+    # SNR points x 6 250 frames = 50 000 frames, one launch per SNR point into the same output buffers
     "cfg3_4x4_etu_mmse": dict(kind="frames", T=4, R=4, N=1024, cp=72, U=600, ct="ETU", fd=370.4, snr=10.0, dens=0.10,
-                              frames=6250),
+                              frames=6250, snr_sweep=(-5.0, 0.0, 5.0, 10.0, 15.0, 20.0, 25.0, 30.0)),
     "cfg1_siso_epa_ls": dict(kind="frames", T=1, R=1, N=1024, cp=72, U=600, ct="EPA", fd=5.56, snr=10.0, dens=0.10,
                              frames=10000),
     # kind "dataset": per-frame uniform choice of type / Doppler / SNR / density (run_phase3_dataset_generation.py:104-107),
@@ -243,6 +245,17 @@ def _pmc_traffic(workload, F, group):
     return None, None
 
 
+def qhull_replan(eng, IP, slots, S, nsc, workers=0):
+    """Give the (device-drawn) pilot patterns in `slots` the REFERENCE's triangulation: scipy.spatial.Delaunay = Qhull, what
+    griddata('linear') builds (src/baseline_estimators.py:65-79), uploaded as simplices; point location and barycentric weights
+    stay on the device (chest_pattern_set_triangulation, the route of every golden test).  Frames through these plans equal
+    the reference's LS / MMSE on the same inputs; the device triangulator's own plans are a valid Delaunay triangulation that
+    differs inside co-circular lattice polygons (`per_frame_patterns.plan_parity`)."""
+    pils = [eng.get_pilots(int(sl)) for sl in slots]
+    for sl, pil, tri in zip(slots, pils, IP.triangulations_iter(pils, S, nsc, workers if len(pils) >= 64 else 0)):
+        eng.set_pattern(int(sl), pil, tri)
+
+
 class Job:
     """Process-group context shared by the legs of one bench process."""
     def __init__(self, args):
@@ -290,6 +303,10 @@ def measure_leg(job, args, workload, group, steps, warmup, frames=None, patterns
     kind = w["kind"]
     T, R, N, cp, U = w["T"], w["R"], w["N"], w["cp"], w["U"]
     F = frames or w["frames"]
+    # launches per step: one per SNR point of a sweep workload (F frames each), else one
+    sweep = tuple(w.get("snr_sweep", ())) if (kind == "frames" and not args.single_snr) else ()
+    sweep = sweep or ((w["snr"],) if "snr" in w else (None,))
+    nrep = len(sweep)
     geom = E.Geometry(fft_size=N, cp_length=cp, num_symbols=14, useful_subcarriers=U, num_tx=T, num_rx=R)
     eng = E.Engine(geom, local)
     S, nsc, G = geom.num_symbols, geom.num_sc, geom.grid
@@ -352,6 +369,15 @@ def measure_leg(job, args, workload, group, steps, warmup, frames=None, patterns
             slots = [eng.pattern_slot(pil, "linear") for pil in pils]
     else:
         workers = 0
+    # Patterns that are SHARED by frames are built outside the timed region, so they take the reference's own triangulation
+    # (Qhull) at no cost to the measurement: the timed frames are then griddata-identical.  A pattern per frame is triangulated
+    # by the device kernel inside the timed step (a valid Delaunay triangulation; divergence measured in `plan_parity`).
+    qhull = device_patterns and not per_step_patterns and args.triangulation == "qhull" and len(slots) > 0 and \
+        not (group == 1 and kind != "fullcov")
+    if qhull:
+        torch.cuda.synchronize()
+        eng.check_status()
+        qhull_replan(eng, IP, slots, S, nsc, workers=min(16, os.cpu_count() or 1))
     torch.cuda.synchronize()
     eng.check_status()
     t_plan = time.perf_counter() - t_plan
@@ -392,8 +418,9 @@ def measure_leg(job, args, workload, group, steps, warmup, frames=None, patterns
             if args.with_metrics:
                 names.append("metrics")
         npil_frames = np.full(F, int(G * w["dens"]), np.int32)
-        descs = E.make_descs(w["ct"], w["fd"], w["snr"], slot_of_frame, n=F)
-        d_first = torch.from_numpy(descs.view(np.uint8).copy()).to(eng.device)
+        d_sweep = [torch.from_numpy(E.make_descs(w["ct"], w["fd"], snr, slot_of_frame, n=F).view(np.uint8).copy()).to(eng.device)
+                   for snr in sweep]
+        d_first = d_sweep[0]
 
     # Output buffers are allocated once and reused by every step (--placement-tries > 1 probes several allocations with
     # the real kernel and keeps the fastest, Engine.place_outputs; the default takes the first allocation).
@@ -452,9 +479,11 @@ def measure_leg(job, args, workload, group, steps, warmup, frames=None, patterns
             for st_ in (sF, sG, sI):
                 main.wait_stream(st_)
         else:
-            if per_step_patterns:
-                eng.build_patterns(0, npil_frames, seed=2024, pattern_ids=np.arange(off, off + F, dtype=np.uint64), method=pf_method)
-            eng.run_frames(d_first, seed=seed, frame_offset=off, outputs=names, out=out, check=False)
+            for j in range(nrep):
+                offj = off * nrep + j * F
+                if per_step_patterns:
+                    eng.build_patterns(0, npil_frames, seed=2024, pattern_ids=np.arange(offj, offj + F, dtype=np.uint64), method=pf_method)
+                eng.run_frames(d_sweep[j], seed=seed, frame_offset=offj, outputs=names, out=out, check=False)
 
     # est-MSE is evaluate_estimator's job, not part of the LS+MMSE step: one extra UNTIMED launch with the fused
     # error-sum output gives the numbers reported under "est_mse" (fullcov: error sums of the stored tensors).
@@ -463,16 +492,22 @@ def measure_leg(job, args, workload, group, steps, warmup, frames=None, patterns
         es = eng.error_sums(out["H"], out["H_mmse"]).double()
         cnt = float(out["H"].numel())
         summ = torch.stack([es[1], es[0], es[0], torch.tensor(cnt, dtype=torch.float64, device=es.device)])
-    else:
+    elif kind == "dataset":
         mse_out = eng.run_frames(d_first, seed=seed, frame_offset=rank * F, outputs=("metrics",))["metrics"].double()
         summ = torch.stack([mse_out[:, 0].sum(), mse_out[:, 1].sum(), mse_out[:, 2].sum(), mse_out[:, 6].sum()])
+    else:
+        per_snr = []
+        for j in range(nrep):
+            m = eng.run_frames(d_sweep[j], seed=seed, frame_offset=rank * F * nrep + j * F, outputs=("metrics",))["metrics"].double()
+            per_snr.append(torch.stack([m[:, 0].sum(), m[:, 1].sum(), m[:, 2].sum(), m[:, 6].sum()]))
+        summ = torch.stack(per_snr).sum(0)
     for i in range(warmup):
         step(i)
     if use_coll:
         dist.barrier()
     torch.cuda.synchronize()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
-    eng.profile_begin(steps * (nch if kind == "fullcov" else 1))   # library-side HIP events around each kernel, on the launch stream
+    eng.profile_begin(steps * (nch if kind == "fullcov" else nrep))   # library-side HIP events around each kernel, on the launch stream
     t0 = time.perf_counter()
     for i in range(steps):
         ev[i][0].record()
@@ -500,10 +535,13 @@ def measure_leg(job, args, workload, group, steps, warmup, frames=None, patterns
     res = None
     if rank == 0:
         taps_ms, kern_ms = kern.get("taps_kernel", 0.0), kern.get("frame_kernel", 0.0)
-        cfgd = {"workload": workload, "frames_per_step_per_gpu": F, "mimo": f"{T}x{R}", "fft_size": N, "pilots": P,
+        cfgd = {"workload": workload, "frames_per_step_per_gpu": F * nrep, "launches_per_step": nrep, "frames_per_launch": F, "mimo": f"{T}x{R}", "fft_size": N, "pilots": P,
                 "pattern_group": group, "patterns": npatterns,
-                "pattern_source": ("device: Philox pilot selection + Delaunay + plan in one launch" + (", rebuilt inside every timed step" if per_step_patterns else ""))
-                if device_patterns else "host: legacy shuffle + Qhull",
+                "pattern_source": (("device: Philox pilot selection; triangulation: Qhull (scipy.spatial.Delaunay, the reference's) on the host, "
+                                    "simplices uploaded, point location + weights on the device" if qhull else
+                                    "device: Philox pilot selection + device Delaunay + plan in one launch" + (", rebuilt inside every timed step" if per_step_patterns else ""))
+                                   if device_patterns else "host: legacy shuffle + Qhull"),
+                "triangulation": ("qhull" if (qhull or not device_patterns) else "device"),
                 "host_plan_build_s": round(t_plan, 2) if not device_patterns else 0.0, "plan_build_s": round(t_plan, 3),
                 "host_plan_workers": workers, "output_placement": placement, "rng": "Philox4x32-10 on device",
                 "outputs": names, "parallelism": f"frames sharded x{world}", "dist_backend": args.dist_backend if use_coll else None,
@@ -522,7 +560,7 @@ def measure_leg(job, args, workload, group, steps, warmup, frames=None, patterns
                         estimators="MMSE(full covariance, W prepared once in float64 on the device)", **extra)
         else:
             bytes_frame = algorithmic_bytes_per_frame(S, nsc, T, R, P, 2)
-            cfgd.update(channel=w["ct"], doppler_hz=w["fd"], snr_db=w["snr"], pilot_density=w["dens"],
+            cfgd.update(channel=w["ct"], doppler_hz=w["fd"], snr_db=(list(sweep) if nrep > 1 else w["snr"]), pilot_density=w["dens"],
                         path="simulate_transmission + LSEstimator.estimate + MMSEEstimator.estimate per frame",
                         estimators="LS(linear)+MMSE(diag)")
         if group == 1 and kind != "fullcov":   # a plan of its own per frame has to be read: 16-B record per RE + 4-B pilot index (SURVEY 8d row 4;
@@ -538,8 +576,14 @@ def measure_leg(job, args, workload, group, steps, warmup, frames=None, patterns
             hbm = bytes_frame * F / (step_ms * 1e-3) / 1e9
             # `achieved` prices the 8 P^2 flop per right-hand side the result represents (4 real multiply-adds per complex one);
             # the 3-multiplication form the kernel runs issues 3/4 of them on the MFMA pipe: `issued_*` is that figure
-            roof = {"bound": "mfma", "achieved": ach, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": ach / MFMA_F32_PEAK_TFLOPS, "issued_TFLOPs": 0.75 * ach, "issued_frac": 0.75 * ach / MFMA_F32_PEAK_TFLOPS,
+            # `achieved` / `frac`: the MFMA work the kernel ISSUES (the 3-multiplication complex product runs 6 P^2 of the 8 P^2
+            # real flop per right-hand side the result represents) -- a roofline fraction, <= 1 by construction; `algorithmic_*`
+            # prices the represented 8 P^2 R flop per frame (R, not R T: one right-hand side per (frame, rx), quirk Q9) and may
+            # exceed the peak for that reason
+            roof = {"bound": "mfma", "achieved": 0.75 * ach, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": 0.75 * ach / MFMA_F32_PEAK_TFLOPS, "issued_TFLOPs": 0.75 * ach, "issued_frac": 0.75 * ach / MFMA_F32_PEAK_TFLOPS,
+                    "algorithmic_TFLOPs": ach, "algorithmic_frac": ach / MFMA_F32_PEAK_TFLOPS,
+                    "flop_note": "issued = 6 P^2 R per frame (3M complex product); algorithmic = 8 P^2 R per frame; R not R*T: tx-replicated right-hand sides (Q9)",
                     "traffic": None, "kernel": "cgemm_w_kernel_3m", "kernel_ms": gemm_ms,
                     "flop_per_frame": 8.0 * P * P * R, "kernels_ms": kern, "call_ms": call_ms,
                     "hbm_whole_step": {"bytes_per_frame": bytes_frame, "achieved_GBps": hbm, "frac": hbm / HBM_PEAK_GBS},
@@ -550,12 +594,12 @@ def measure_leg(job, args, workload, group, steps, warmup, frames=None, patterns
             # frac: the dominant kernel alone (algorithmic bytes / its own average duration); step_frac: the same bytes over the
             # whole step as timed (every kernel of the step, launch gaps and -- with per-frame patterns -- the pattern kernel)
             roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "step_frac": bytes_frame * F / (dt / steps) / 1e9 / HBM_PEAK_GBS,
+                    "frac": achieved / HBM_PEAK_GBS, "step_frac": bytes_frame * F * nrep / (dt / steps) / 1e9 / HBM_PEAK_GBS,
                     "traffic": traffic, "traffic_source": tsrc, "kernel": "frame_slab_kernel",
                     "kernel_ms": kern_ms, "taps_kernel_ms": taps_ms, "call_ms": call_ms, "bytes_per_frame": bytes_frame}
         s = summ.cpu().numpy()
         res = {
-            "metric": "OFDM frames/sec (LS+MMSE)", "value": F * world * steps / dt, "unit": "frames/s",
+            "metric": "OFDM frames/sec (LS+MMSE)", "value": F * nrep * world * steps / dt, "unit": "frames/s",
             "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": dt / steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": cfgd, "roofline": roof,
@@ -565,6 +609,22 @@ def measure_leg(job, args, workload, group, steps, warmup, frames=None, patterns
                               "nmse_db_ls": float(10 * np.log10(s[1] / s[0])), "nmse_db_mmse": float(10 * np.log10(s[2] / s[0]))}
             if kind == "fullcov":
                 res["est_mse"].pop("ls"); res["est_mse"].pop("nmse_db_ls")
+        if kind == "frames" and nrep > 1:
+            # per-SNR frame-averaged MSE of rank 0's frames (evaluate_estimator's 'mse') beside the REAL reference's curve
+            # (tests/golden/snr_sweep_ref_4x4.json: the loop of test_phase2_snr_sweep.py:18-64, 50 frames per SNR; other random frames)
+            ps = torch.stack(per_snr).cpu().numpy()
+            curve = {"snr_db": list(sweep), "frames_per_snr": F, "mse_ls": (ps[:, 1] / ps[:, 3]).tolist(), "mse_mmse": (ps[:, 2] / ps[:, 3]).tolist(),
+                     "nmse_db_ls": (10 * np.log10(ps[:, 1] / ps[:, 0])).tolist(), "nmse_db_mmse": (10 * np.log10(ps[:, 2] / ps[:, 0])).tolist()}
+            try:
+                ref = json.load(open(os.path.join(ROOT, "tests", "golden", "snr_sweep_ref_4x4.json")))
+                if ref["mimo"] == f"{T}x{R}" and [float(r["snr_db"]) for r in ref["snr"]] == [float(x) for x in sweep]:
+                    curve["reference"] = {"source": "tests/golden/snr_sweep_ref_4x4.json (the reference itself, %d frames per SNR)" % ref["frames_per_snr"],
+                                          "mse_ls": [r["mse_ls"] for r in ref["snr"]], "mse_mmse": [r["mse_mmse"] for r in ref["snr"]],
+                                          "mse_ls_stderr": [r["mse_ls_std"] / ref["frames_per_snr"] ** 0.5 for r in ref["snr"]],
+                                          "mse_mmse_stderr": [r["mse_mmse_std"] / ref["frames_per_snr"] ** 0.5 for r in ref["snr"]]}
+            except Exception:
+                pass
+            res["snr_sweep"] = curve
         if cpu:
             res["cpu_baseline"] = cpu_baseline(workload)
     # hand the leg's HBM back before the next one allocates
@@ -582,7 +642,10 @@ def _brief(res):
     if "plan_build_kernel_ms" in res["config"]:
         b["pattern_kernel_ms"] = res["config"]["plan_build_kernel_ms"]
     if r["bound"] == "mfma":
-        b["issued_frac"] = r["issued_frac"]; b["kernels_ms"] = r["kernels_ms"]
+        b["issued_frac"] = r["issued_frac"]; b["algorithmic_frac"] = r["algorithmic_frac"]; b["kernels_ms"] = r["kernels_ms"]
+    if "snr_sweep" in res:
+        b["snr_sweep"] = res["snr_sweep"]
+    b["triangulation"] = res["config"].get("triangulation")
     return b
 
 
@@ -645,8 +708,15 @@ def run(args):
                     "value": pf["value"], "ms_per_step": pf["ms_per_step"], "frac": r["step_frac"],
                     "pattern_kernel_ms": pf["config"].get("plan_build_kernel_ms"), "frame_kernel_ms": r["kernel_ms"],
                     "taps_kernel_ms": r["taps_kernel_ms"], "frame_kernel_frac": r["frac"], "bytes_per_frame": r["bytes_per_frame"],
-                    "plan_format": pf["config"].get("plan_format"), "steps": pf["steps"],
+                    "plan_format": pf["config"].get("plan_format"), "steps": pf["steps"], "triangulation": "device",
                     "note": "frac = bytes_per_frame x frames/s / 8 TB/s over the WHOLE step (pattern kernel + taps + frame kernel)"}
+                # how far the device triangulator's plans are from griddata's on the same frames (tools/plan_parity.py; untimed)
+                try:
+                    sys.path.insert(0, os.path.join(ROOT, "tools"))
+                    import plan_parity
+                    res["per_frame_patterns"]["plan_parity"] = plan_parity.measure(P=pf["config"]["pilots"], patterns=64, device=job.local)
+                except Exception as e:                                   # noqa: BLE001 -- reported in place of the record
+                    res["per_frame_patterns"]["plan_parity"] = {"error": f"{type(e).__name__}: {e}"}
         also = {}
         for name, grp in EXTRA_LEGS:
             rec, err = leg(name, grp, 5, 2)
@@ -676,12 +746,17 @@ def main():
     ap.add_argument("--patterns", default="device", choices=["device", "host"],
                     help="device: pilot patterns drawn, triangulated and planned on the GPU (default); host: legacy np.random "
                          "shuffle + Qhull on the host cores")
+    ap.add_argument("--triangulation", default="qhull", choices=["qhull", "device"],
+                    help="patterns SHARED by frames (built before the timed region): qhull = the reference's triangulation from "
+                         "scipy.spatial.Delaunay, uploaded as simplices (default: the timed frames equal griddata's); device = the "
+                         "device triangulator's.  A pattern per frame (--pattern-group 1) is always triangulated on the device")
     ap.add_argument("--plan-workers", type=int, default=0, help="host processes for plan building with --patterns host (0 = min(16, cores))")
     ap.add_argument("--placement-tries", type=int, default=1,
                     help="candidate allocations per output tensor group (1 = take the first allocation, the default; "
                          ">1 probes placements with the real kernel and keeps the fastest)")
     ap.add_argument("--pipeline-chunks", type=int, default=1,
                     help="cfg5: chunks of the batch pipelined over three streams (frame kernel | MFMA filter | interpolation); 1 = in sequence")
+    ap.add_argument("--single-snr", action="store_true", help="cfg3: one launch at SNR 10 dB per step instead of the eight-point sweep")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-legs", action="store_true",
                     help="default invocation only: skip the per_frame_patterns leg and the `also` legs of the other workloads")

@@ -82,6 +82,9 @@ SIGNATURES = {
     "chest_equalize": (_i32, [_vp, _vp, _i32, _vp, _vp, _i32, _vp]),
     "chest_tdl_apply": (_i32, [_vp, _vp, _i32, _i64, _i32, _i32, _vp, _vp, _vp]),
     "chest_pack_ml_inputs": (_i32, [_vp, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp]),
+    "chest_ml_stats_workspace_bytes": (_i64, []),
+    "chest_ml_dataset_stats": (_i32, [_vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _i64]),
+    "chest_pack_ml_training": (_i32, [_vp, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp]),
     "chest_qam_constellation": (_i32, [_i32, _vp, _vp]),
     "chest_qam_modulate": (_i32, [_vp, _vp, _i32, _i64, _vp, _i32, _vp]),
     "chest_qam_demodulate": (_i32, [_vp, _vp, _i32, _i64, _i32, _vp, _vp]),

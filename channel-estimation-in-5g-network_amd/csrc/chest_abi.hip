@@ -527,6 +527,27 @@ int chest_pack_ml_inputs(chest_ctx* ctx, void* stream, int32_t B, const float* r
     return launch_pack_ml(ctx, (hipStream_t)stream, B, rx, H_ls, H_true, mask, normalize, inputs, targets);
 }
 
+int64_t chest_ml_stats_workspace_bytes(void) { return ml_stats_workspace_bytes(); }
+
+int chest_ml_dataset_stats(chest_ctx* ctx, void* stream, int32_t B, const float* rx, const float* H_ls, const float* H_true,
+                           double* stats, void* workspace, int64_t workspace_bytes) {
+    if (!ctx || B < 1 || !rx || !H_ls || !H_true || !stats || !workspace) { set_error("chest_ml_dataset_stats: bad argument"); return CHEST_EINVAL; }
+    CHEST_GUARD(ctx);
+    return launch_ml_stats(ctx, (hipStream_t)stream, B, rx, H_ls, H_true, stats, workspace, workspace_bytes);
+}
+
+int chest_pack_ml_training(chest_ctx* ctx, void* stream, int32_t B, const float* rx, const float* H_ls, const float* H_true,
+                           const void* mask, int32_t mask_is_f32, int32_t mode, const double* stats, float* inputs, float* targets,
+                           float* mask_out) {
+    if (!ctx || B < 0 || mode < 0 || mode > 2 || (mode != 0 && !stats) ||
+        (B > 0 && (!rx || !H_ls || !H_true || !mask || !inputs || !targets))) {
+        set_error("chest_pack_ml_training: bad argument (mode 0 raw / 1 dataset mean+std / 2 per-tensor |x| std; stats needed for 1, 2)");
+        return CHEST_EINVAL;
+    }
+    CHEST_GUARD(ctx);
+    return launch_pack_train(ctx, (hipStream_t)stream, B, rx, H_ls, H_true, mask, mask_is_f32, mode, stats, inputs, targets, mask_out);
+}
+
 int chest_qam_constellation(int32_t M, double* points, int32_t* gray_map) { return qam_constellation_host(M, points, gray_map); }
 
 int chest_qam_modulate(chest_ctx* ctx, void* stream, int32_t M, int64_t n, const uint8_t* bits, int32_t wide, void* symbols) {

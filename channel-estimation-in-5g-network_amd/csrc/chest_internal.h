@@ -170,6 +170,12 @@ int launch_tdl(chest_ctx* ctx, hipStream_t st, int32_t type, int64_t ns, int32_t
                float* y);
 int launch_pack_ml(chest_ctx* ctx, hipStream_t st, int32_t B, const float* rx, const float* Hls, const float* Htrue,
                    const uint8_t* mask, int32_t normalize, float* inputs, float* targets);
+int64_t ml_stats_workspace_bytes();
+int launch_ml_stats(chest_ctx* ctx, hipStream_t st, int32_t B, const float* rx, const float* Hls, const float* Htrue, double* stats,
+                    void* workspace, int64_t workspace_bytes);
+int launch_pack_train(chest_ctx* ctx, hipStream_t st, int32_t B, const float* rx, const float* Hls, const float* Htrue,
+                      const void* mask, int32_t mask_is_f32, int32_t mode, const double* stats, float* inputs, float* targets,
+                      float* mask_out);
 int launch_plan_locate(chest_ctx* ctx, hipStream_t st, const int32_t* d_pilot_idx, const int32_t* d_simp, int32_t ns, void* d_packed,
                        void* d_plan);
 struct QamTable;

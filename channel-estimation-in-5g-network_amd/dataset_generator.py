@@ -321,6 +321,42 @@ def prepare_ml_inputs_batch(dataset: Dict, config: Dict, normalize: bool = True)
     return eng.pack_ml_inputs(dataset['rx_symbols'], dataset['H_ls'], dataset['H_true'], mask, normalize)
 
 
+class TrainingDataset:
+    """The reference's training-side loaders on the device: ``train.ChannelDataset`` (src/train.py:22-94,
+    ``style="train"``: dataset-level mean / std per tensor) and ``run_phase4_training.ChannelEstimationDataset``
+    (run_phase4_training.py:33-112, ``style="phase4"``: std of |x| + 1e-8, no mean) -- same constructor meaning (a ``.npz`` path
+    or an already stacked dict with rx_symbols / H_ls / H_true / pilot_mask), the same statistic attributes, ``len()`` and
+    ``ds[i] -> (inputs (5, S, nsc), targets (2, S, nsc), pilot_mask (S, nsc))``, but every sample is packed by ONE launch at
+    construction and handed out as float32 DEVICE tensors: a training loop reads HBM, not a 1-TB ``.npz`` round trip.
+    ``stats_from`` lets a validation / test split reuse the training split's statistics (the reference recomputes per file)."""
+
+    def __init__(self, data, config: Dict, normalize: bool = True, style: str = "train", stats_from: "TrainingDataset" = None):
+        if style not in ("train", "phase4"):
+            raise ValueError(f"unknown loader style {style!r}")
+        if not isinstance(data, dict):
+            with np.load(data, allow_pickle=False) as z:
+                data = {k: z[k] for k in ('rx_symbols', 'H_ls', 'H_true', 'pilot_mask')}
+        eng = _engine.get_engine(_geometry_from_config(config))
+        self.normalize, self.style = normalize, style
+        self.num_samples = len(data['rx_symbols'])
+        self.stats = None
+        if normalize:
+            self.stats = stats_from.stats if stats_from is not None else eng.ml_dataset_stats(data['rx_symbols'], data['H_ls'], data['H_true'])
+            s = self.stats.cpu().numpy()
+            if style == "train":
+                (self.rx_mean, self.rx_std, self.H_ls_mean, self.H_ls_std, self.H_true_mean, self.H_true_std) = (float(v) for v in s[:6])
+            else:
+                self.rx_std, self.H_ls_std, self.H_true_std = (float(v) for v in s[6:9])
+        self.inputs, self.targets, self.pilot_mask = eng.pack_ml_training(
+            data['rx_symbols'], data['H_ls'], data['H_true'], data['pilot_mask'], mode=(style if normalize else "raw"), stats=self.stats)
+
+    def __len__(self):
+        return self.num_samples
+
+    def __getitem__(self, idx):
+        return self.inputs[idx], self.targets[idx], self.pilot_mask[idx]
+
+
 def main():
     """CLI with the reference's flags (src/dataset_generator.py:230-315) plus --native."""
     import yaml

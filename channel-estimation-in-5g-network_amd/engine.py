@@ -737,6 +737,65 @@ class Engine:
                 "chest_pack_ml_inputs")
         return inputs, targets
 
+    # ---- training-side packing (src/train.py:22-94, run_phase4_training.py:60-112) ------------------------------------------
+    ML_STATS_FIELDS = ("rx_mean", "rx_std", "H_ls_mean", "H_ls_std", "H_true_mean", "H_true_std",
+                       "phase4_rx_std", "phase4_H_ls_std", "phase4_H_true_std")
+
+    def _ml_check(self, rx, H_ls, H_true):
+        g = self.geom
+        rxd, ls, ht = self._c64(rx), self._c64(H_ls), self._c64(H_true)
+        B = rxd.shape[0]
+        if rxd.dim() != 4 or tuple(rxd.shape[1:]) != (g.num_symbols, g.num_rx, g.num_sc) or \
+                tuple(ls.shape) != (B, g.num_symbols, g.num_rx, g.num_tx, g.num_sc) or ls.shape != ht.shape:
+            raise ValueError("rx_symbols [N,S,R,nsc] and H_ls / H_true [N,S,R,T,nsc] expected for this engine geometry")
+        return rxd, ls, ht, B
+
+    def ml_dataset_stats(self, rx, H_ls, H_true):
+        """Dataset-level normalisation statistics of both reference loaders over the first antenna pair, float64 on the
+        device: a [9] tensor in ``ML_STATS_FIELDS`` order (src/train.py:41-58; run_phase4_training.py:65-76)."""
+        rxd, ls, ht, B = self._ml_check(rx, H_ls, H_true)
+        if B < 1:
+            raise ValueError("statistics of an empty dataset")
+        stats = torch.empty(9, dtype=torch.float64, device=self.device)
+        nbytes = N.lib().chest_ml_stats_workspace_bytes()
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        N.check(N.lib().chest_ml_dataset_stats(self._h, self._stream(), B, rxd.data_ptr(), ls.data_ptr(), ht.data_ptr(),
+                                               stats.data_ptr(), ws.data_ptr(), nbytes), "chest_ml_dataset_stats")
+        torch.cuda.current_stream(self.device).synchronize()       # ws is freed on return
+        return stats
+
+    def pack_ml_training(self, rx, H_ls, H_true, pilot_mask, mode="train", stats=None):
+        """``__getitem__`` of the reference's training loaders for a whole dataset in one launch: (inputs [N,5,S,nsc], targets
+        [N,2,S,nsc], pilot_mask [N,S,nsc]) float32 device tensors.  ``mode``: "raw" (normalize=False), "train" ((x - mean) /
+        (std + 1e-8) with dataset-level statistics, src/train.py:63-94) or "phase4" (x / std(|x|), run_phase4_training.py:81-112);
+        ``stats`` = ``ml_dataset_stats`` of the dataset the statistics are to come from (computed from these tensors if None)."""
+        code = {"raw": 0, "train": 1, "phase4": 2}.get(mode)
+        if code is None:
+            raise ValueError(f"unknown packing mode {mode!r}")
+        g = self.geom
+        rxd, ls, ht, B = self._ml_check(rx, H_ls, H_true)
+        if isinstance(pilot_mask, torch.Tensor):
+            m = pilot_mask.to(self.device).contiguous()
+            if m.dtype not in (torch.float32, torch.uint8):
+                m = m.to(torch.float32)
+        else:
+            a = np.asarray(pilot_mask)
+            m = self._dev(a, torch.uint8 if a.dtype in (np.uint8, np.bool_) else torch.float32)
+        if tuple(m.shape) != (B, g.num_symbols, g.num_sc):
+            raise ValueError("pilot_mask must be [N,S,nsc]")
+        if code and stats is None:
+            stats = self.ml_dataset_stats(rxd, ls, ht)
+        if stats is not None and (stats.dtype != torch.float64 or stats.numel() != 9 or stats.device != self.device):
+            raise ValueError("stats must be the [9] float64 device tensor of ml_dataset_stats")
+        inputs = torch.empty(B, 5, g.num_symbols, g.num_sc, dtype=torch.float32, device=self.device)
+        targets = torch.empty(B, 2, g.num_symbols, g.num_sc, dtype=torch.float32, device=self.device)
+        mask_out = torch.empty(B, g.num_symbols, g.num_sc, dtype=torch.float32, device=self.device)
+        N.check(N.lib().chest_pack_ml_training(self._h, self._stream(), B, rxd.data_ptr(), ls.data_ptr(), ht.data_ptr(),
+                                               m.data_ptr(), int(m.dtype == torch.float32), code,
+                                               None if stats is None else stats.data_ptr(), inputs.data_ptr(), targets.data_ptr(),
+                                               mask_out.data_ptr()), "chest_pack_ml_training")
+        return inputs, targets, mask_out
+
     def ofdm_modulate(self, symbols):
         g = self.geom
         s = self._c64(symbols)

@@ -284,6 +284,27 @@ int chest_tdl_apply(chest_ctx* ctx, void* stream, int32_t channel_type, int64_t 
 int chest_pack_ml_inputs(chest_ctx* ctx, void* stream, int32_t num_frames, const float* rx, const float* H_ls,
                          const float* H_true, const uint8_t* mask, int32_t normalize, float* inputs, float* targets);
 
+/* Training-side packing of dataset records, for the whole batch on the device.
+ *   chest_ml_dataset_stats   the dataset-level statistics of the reference's two loaders over the first-antenna-pair slices
+ *                            rx[:, :, 0, :], H_ls[:, :, 0, 0, :], H_true[:, :, 0, 0, :]; stats = 9 DEVICE doubles:
+ *                            [0..5] rx_mean, rx_std, H_ls_mean, H_ls_std, H_true_mean, H_true_std as train.ChannelDataset.
+ *                            _compute_normalization_stats (src/train.py:41-58: the mean of the real-part and imaginary-part
+ *                            mean / population std); [6..8] rx_std, H_ls_std, H_true_std as run_phase4_training.
+ *                            ChannelEstimationDataset._compute_stats (run_phase4_training.py:65-76: np.std(np.abs(x)) + 1e-8).
+ *                            float64 sums, deterministic order; workspace >= chest_ml_stats_workspace_bytes().
+ *   chest_pack_ml_training   __getitem__ of those loaders for every frame (src/train.py:63-94, run_phase4_training.py:81-112):
+ *                            inputs [B][5][S][nsc] f32 = (rx re, rx im, H_ls re, H_ls im, mask), targets [B][2][S][nsc] f32 =
+ *                            H_true re / im, mask_out [B][S][nsc] f32 (may be NULL).  mode 0: no normalisation; 1: (x - mean) /
+ *                            (std + 1e-8) per tensor with stats[0..5]; 2: x / std with stats[6..8].  mask: u8 [B][S][nsc]
+ *                            (mask_is_f32 = 0) or f32 (1, the dataset schema's pilot_mask).  rx [B][S][R][nsc], H_ls / H_true
+ *                            [B][S][R][T][nsc] c64. */
+int64_t chest_ml_stats_workspace_bytes(void);
+int chest_ml_dataset_stats(chest_ctx* ctx, void* stream, int32_t num_frames, const float* rx, const float* H_ls,
+                           const float* H_true, double* stats, void* workspace, int64_t workspace_bytes);
+int chest_pack_ml_training(chest_ctx* ctx, void* stream, int32_t num_frames, const float* rx, const float* H_ls,
+                           const float* H_true, const void* mask, int32_t mask_is_f32, int32_t mode, const double* stats,
+                           float* inputs, float* targets, float* mask_out);
+
 /* QPSK / 16-QAM helpers (src/utils.py:71-158).  M = 4 or 16, anything else -> CHEST_EINVAL (the reference raises
  * NotImplementedError, :104, :138).  Bits are one byte per bit (0 / non-zero), most significant bit of a symbol first
  * (:87-90, :148-151); `wide` selects complex128 (1) or complex64 (0) symbols.  Decisions are taken in float64.

@@ -370,6 +370,45 @@ def bit_error_rate(tx_bits, rx_bits):
 # --------------------------------------------------------------------------------------------
 # "faithful" mode pieces: same algorithmic structure (and cost profile) as the reference, used
 # only for the cpu_baseline timing in bench.py.
+# ---- training-side feature packing --------------------------------------------------------------------------
+def ml_first_pair(rx_symbols, H_ls, H_true):
+    """The slices every reference loader works on: rx[:, :, 0, :], H_ls[:, :, 0, 0, :], H_true[:, :, 0, 0, :]
+    (src/train.py:43-46, :66-68; run_phase4_training.py:68-69, :84-86)."""
+    return np.asarray(rx_symbols)[:, :, 0, :], np.asarray(H_ls)[:, :, 0, 0, :], np.asarray(H_true)[:, :, 0, 0, :]
+
+
+def ml_train_stats(rx_symbols, H_ls, H_true):
+    """(rx_mean, rx_std, H_ls_mean, H_ls_std, H_true_mean, H_true_std) of train.ChannelDataset._compute_normalization_stats
+    (src/train.py:41-58): the mean of the real-part and the imaginary-part statistic, population std; float64 here."""
+    out = []
+    for x in ml_first_pair(rx_symbols, H_ls, H_true):
+        re, im = x.real.astype(np.float64), x.imag.astype(np.float64)
+        out += [0.5 * (re.mean() + im.mean()), 0.5 * (re.std() + im.std())]
+    return np.array(out)
+
+
+def ml_phase4_stats(rx_symbols, H_ls, H_true):
+    """(rx_std, H_ls_std, H_true_std) of run_phase4_training.ChannelEstimationDataset._compute_stats (:65-76): std(|x|) + 1e-8."""
+    return np.array([np.std(np.abs(x.astype(np.complex128))) + 1e-8 for x in ml_first_pair(rx_symbols, H_ls, H_true)])
+
+
+def ml_pack_training(rx_symbols, H_ls, H_true, pilot_mask, mode="train"):
+    """inputs [N,5,S,nsc], targets [N,2,S,nsc] (float64) as the loaders' __getitem__ stack them (src/train.py:63-94;
+    run_phase4_training.py:81-112): channels (rx re, rx im, H_ls re, H_ls im, mask); mode "raw" / "train" / "phase4"."""
+    rx, ls, ht = (x.astype(np.complex128) for x in ml_first_pair(rx_symbols, H_ls, H_true))
+    ri = lambda z: np.stack([z.real, z.imag], axis=1)
+    a, b, c = ri(rx), ri(ls), ri(ht)
+    if mode == "train":
+        st = ml_train_stats(rx_symbols, H_ls, H_true)
+        a, b, c = (a - st[0]) / (st[1] + 1e-8), (b - st[2]) / (st[3] + 1e-8), (c - st[4]) / (st[5] + 1e-8)
+    elif mode == "phase4":
+        st = ml_phase4_stats(rx_symbols, H_ls, H_true)
+        a, b, c = a / st[0], b / st[1], c / st[2]
+    elif mode != "raw":
+        raise ValueError(mode)
+    return np.concatenate([a, b, np.asarray(pilot_mask, dtype=np.float64)[:, None]], axis=1), c
+
+
 # --------------------------------------------------------------------------------------------
 def channel_frequency_response_faithful(model_type, doppler_hz, fft_size, cp_length, num_symbols,
                                         useful_subcarriers, subcarrier_spacing, u_angle, u_phase):

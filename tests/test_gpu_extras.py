@@ -74,6 +74,60 @@ def test_pack_ml_inputs_batch_matches_per_sample_helper():
             assert np.array_equal(xi[i][..., 4], ds["pilot_mask"][i])
 
 
+def _ml_fixture():
+    import os
+    from conftest import GOLDEN
+    g = np.load(os.path.join(GOLDEN, "ml_packing.npz"))
+    cfg = {"ofdm": {"fft_size": int(g["fft_size"]), "cp_length": int(g["cp_length"]), "subcarrier_spacing": 15000,
+                    "num_symbols": int(g["num_symbols"]), "useful_subcarriers": int(g["useful_subcarriers"])},
+           "mimo": {"num_tx_antennas": int(g["num_tx"]), "num_rx_antennas": int(g["num_rx"])}, "channel": {"carrier_freq": 2.0e9}}
+    data = {k: g[k] for k in ("rx_symbols", "H_ls", "H_true", "pilot_mask")}
+    return g, cfg, data
+
+
+def test_prepare_ml_inputs_against_the_reference_fixture():
+    """tests/golden/ml_packing.npz holds the outputs of the REFERENCE's dataset_generator.prepare_ml_inputs (both `normalize`
+    modes, src/dataset_generator.py:183-227) on eight frames the reference itself simulated (tools/make_golden_r4.py): the GPU
+    batch kernel and the per-sample helper are both compared with those, not with each other."""
+    g, cfg, data = _ml_fixture()
+    for normalize, ki, kt in ((True, "prep_norm_inputs", "prep_norm_targets"), (False, "prep_raw_inputs", "prep_raw_targets")):
+        xi, yt = dg.prepare_ml_inputs_batch(data, cfg, normalize=normalize)
+        assert tuple(xi.shape) == g[ki].shape and tuple(yt.shape) == g[kt].shape
+        assert np.max(np.abs(xi.cpu().numpy() - g[ki])) < 2e-6 * np.max(np.abs(g[ki]))
+        assert np.max(np.abs(yt.cpu().numpy() - g[kt])) < 2e-6 * np.max(np.abs(g[kt]))
+        for i in range(len(g[ki])):
+            a, b = dg.prepare_ml_inputs({k: v[i] for k, v in data.items()}, normalize=normalize)
+            assert np.max(np.abs(a - g[ki][i])) < 2e-6 * np.max(np.abs(g[ki][i])) and np.max(np.abs(b - g[kt][i])) < 2e-6 * np.max(np.abs(g[kt][i]))
+
+
+@pytest.mark.parametrize("style,normalize,ki,kt", [("train", True, "train_inputs", "train_targets"), ("train", False, "train_raw_inputs", "train_raw_targets"),
+                                                   ("phase4", True, "p4_inputs", "p4_targets")])
+def test_training_side_packing_against_the_reference_loaders(style, normalize, ki, kt):
+    """SURVEY 8f-2's training-side packing: (N, 5, S, nsc) / (N, 2, S, nsc) float32, channels first, with DATASET-level statistics,
+    against the outputs of the reference's own loaders -- train.ChannelDataset.__getitem__ (src/train.py:22-94) and
+    run_phase4_training.ChannelEstimationDataset.__getitem__ (run_phase4_training.py:60-112) -- recorded in
+    tests/golden/ml_packing.npz.  Tolerance 2e-6 of the tensor's scale (the reference normalises in float32)."""
+    g, cfg, data = _ml_fixture()
+    ds = dg.TrainingDataset(data, cfg, normalize=normalize, style=style)
+    assert len(ds) == 8 and tuple(ds.inputs.shape) == g[ki].shape and tuple(ds.targets.shape) == g[kt].shape
+    assert np.max(np.abs(ds.inputs.cpu().numpy() - g[ki])) < 2e-6 * np.max(np.abs(g[ki]))
+    assert np.max(np.abs(ds.targets.cpu().numpy() - g[kt])) < 2e-6 * np.max(np.abs(g[kt]))
+    assert np.array_equal(ds.pilot_mask.cpu().numpy(), g["pilot_mask"])
+    x, y, m = ds[3]
+    assert tuple(x.shape) == (5, 14, 71) and tuple(y.shape) == (2, 14, 71) and tuple(m.shape) == (14, 71)
+    assert np.array_equal(x[4].cpu().numpy(), g["pilot_mask"][3])
+    if normalize and style == "train":
+        got = [ds.rx_mean, ds.rx_std, ds.H_ls_mean, ds.H_ls_std, ds.H_true_mean, ds.H_true_std]
+        assert np.allclose(got, g["train_stats"], rtol=2e-6, atol=1e-9)             # the reference's statistics are float32
+    if normalize and style == "phase4":
+        assert np.allclose([ds.rx_std, ds.H_ls_std, ds.H_true_std], g["p4_stats"], rtol=2e-6)
+    # a uint8 mask (the engine's own pilot_mask output) packs the same; a second split may reuse the first one's statistics
+    data8 = dict(data, pilot_mask=(data["pilot_mask"] != 0).astype(np.uint8))
+    ds8 = dg.TrainingDataset(data8, cfg, normalize=normalize, style=style, stats_from=ds if normalize else None)
+    import torch
+    assert torch.equal(ds8.inputs, ds.inputs) and torch.equal(ds8.targets, ds.targets)
+
+
 # ---- QPSK / 16-QAM / BER helpers (src/utils.py:71-158): bit-exact integer work -------------------------------------
 U = importlib.import_module(PKG + ".utils")
 

@@ -193,3 +193,16 @@ def test_estimate_covariance_restates_np_cov_over_flattened_leading_dims():
     import torch
     assert np.array_equal(est.estimate_covariance(torch.from_numpy(h)), want)
     assert np.array_equal(est.estimate_covariance(h.real), np.cov(h.real.reshape(-1, 17), rowvar=False))
+
+
+@pytest.mark.parametrize("mode,ki,kt", [("train", "train_inputs", "train_targets"), ("raw", "train_raw_inputs", "train_raw_targets"),
+                                        ("phase4", "p4_inputs", "p4_targets")])
+def test_training_side_packing_restatement_matches_the_reference_loaders(mode, ki, kt):
+    """oracle.ml_pack_training against the outputs of the reference's train.ChannelDataset / run_phase4_training.
+    ChannelEstimationDataset recorded in tests/golden/ml_packing.npz (tools/make_golden_r4.py); the reference computes in float32."""
+    g = np.load(os.path.join(GOLDEN, "ml_packing.npz"))
+    x, y = O.ml_pack_training(g["rx_symbols"], g["H_ls"], g["H_true"], g["pilot_mask"], mode)
+    assert x.shape == g[ki].shape and y.shape == g[kt].shape
+    assert np.max(np.abs(x - g[ki])) < 2e-6 * np.max(np.abs(g[ki])) and np.max(np.abs(y - g[kt])) < 2e-6 * np.max(np.abs(g[kt]))
+    assert np.allclose(O.ml_train_stats(g["rx_symbols"], g["H_ls"], g["H_true"]), g["train_stats"], rtol=2e-6, atol=1e-9)
+    assert np.allclose(O.ml_phase4_stats(g["rx_symbols"], g["H_ls"], g["H_true"]), g["p4_stats"], rtol=2e-6)

@@ -1,0 +1,93 @@
+#!/usr/bin/env python3
+"""How far the device triangulator's interpolation plans are from griddata's, measured on the frames themselves.
+
+The batch path's `pattern_build_kernel` yields A valid Delaunay triangulation of the pilots; the reference's
+`griddata('linear')` (src/baseline_estimators.py:65-79) uses Qhull's.  On the integer pilot lattice the two differ inside
+co-circular polygons, where any triangulation is Delaunay.  `measure` runs the SAME frames -- same pilots, same
+Philox draws, hence the same tx / H / rx and the same LS estimates at the pilots -- once through the device-built plans and once
+through plans located in Qhull's simplices (`chest_pattern_set_triangulation`, the route of every golden test) and reports
+
+  re_frac_gt_1e5   fraction of H_ls elements whose difference exceeds 1e-5 x max|H_ls|  (north_star's tolerance)
+  rel_l2           ||H_ls(device plan) - H_ls(Qhull plan)|| / ||H_ls(Qhull plan)||
+  mse_rel_delta    |MSE_ls(device) - MSE_ls(Qhull)| / MSE_ls(Qhull) per frame: mean and max  (evaluate_estimator's 'mse')
+  shared_triangles fraction of the device triangles that are also Qhull's
+
+Used by tests/test_gpu_patterns.py (asserted bounds) and by bench.py (`per_frame_patterns.plan_parity`).  Stand-alone:
+    python tools/plan_parity.py [--pilots 838] [--patterns 64]
+"""
+import importlib
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+PKG = "channel-estimation-in-5g-network_amd"
+
+
+def measure(P=838, patterns=64, geometry=None, channel="EVA", doppler_hz=111.1, snr_db=10.0, seed=2024, first_id=0,
+            method="linear_compact", device=0):
+    import torch
+    E = importlib.import_module(PKG + ".engine")
+    IP = importlib.import_module(PKG + ".interp_plan")
+    geom = geometry or E.Geometry()
+    S, nsc = geom.num_symbols, geom.num_sc
+    dev = E.Engine(geom, device)
+    ref = E.Engine(geom, device)
+    try:
+        if method == "linear_compact" and not dev.compact_plans_supported:
+            method = "linear"
+        ids = np.arange(first_id, first_id + patterns, dtype=np.uint64)
+        slots, simp, cnt = dev.build_patterns(0, [P] * patterns, seed=seed, pattern_ids=ids, method="linear", return_simplices=True)
+        dev.check_status()
+        simp, cnt = simp.cpu().numpy(), cnt.cpu().numpy()
+        pils = [dev.get_pilots(int(s)) for s in slots]
+        if method != "linear":                                   # the format the per-frame path reads (same triangulation)
+            dev.close()
+            dev = E.Engine(geom, device)
+            slots = dev.build_patterns(0, [P] * patterns, seed=seed, pattern_ids=ids, method=method)
+            dev.check_status()
+        shared = []
+        for j, pil in enumerate(pils):
+            ps, pk = np.unravel_index(pil.astype(np.int64), (S, nsc))
+            q = IP.linear_triangulation(ps, pk)
+            ref.set_pattern(j, pil, q)
+            qs = {tuple(sorted(t)) for t in q.tolist()}
+            mine = [tuple(sorted(t)) for t in simp[j, :cnt[j]].tolist()]
+            shared.append(sum(t in qs for t in mine) / max(1, len(mine)))
+        names = ("H", "rx", "H_ls", "H_mmse", "metrics")
+        d = E.make_descs(channel, doppler_hz, snr_db, np.arange(patterns, dtype=np.int32), n=patterns)
+        a = dev.run_frames(d, seed=seed, frame_offset=first_id, outputs=names)
+        b = ref.run_frames(d, seed=seed, frame_offset=first_id, outputs=names)
+        torch.cuda.synchronize()
+        assert torch.equal(a["H"], b["H"]) and torch.equal(a["rx"], b["rx"]), "the two routes must see identical frames"
+        out = {"pilots": int(P), "patterns": int(patterns), "plan_format": method, "shared_triangles": float(np.mean(shared))}
+        for key in ("H_ls", "H_mmse"):
+            x, y = a[key].reshape(patterns, -1), b[key].reshape(patterns, -1)
+            diff = (x - y).abs()
+            scale = float(y.abs().max())
+            out[key] = {"re_frac_gt_1e5": float((diff > 1e-5 * scale).double().mean()),
+                        "max_over_scale": float(diff.max()) / scale,
+                        "rel_l2": float(torch.linalg.vector_norm(diff.double()) / torch.linalg.vector_norm(y.abs().double()))}
+        ma, mb = a["metrics"].double().cpu().numpy(), b["metrics"].double().cpu().numpy()
+        for key, col in (("ls", 1), ("mmse", 2)):
+            rel = np.abs(ma[:, col] - mb[:, col]) / mb[:, col]
+            out["mse_rel_delta_" + key] = {"mean": float(rel.mean()), "max": float(rel.max()),
+                                           "batch": float(abs(ma[:, col].sum() - mb[:, col].sum()) / mb[:, col].sum())}
+        return out
+    finally:
+        dev.close()
+        ref.close()
+
+
+if __name__ == "__main__":
+    import argparse
+    import json
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--pilots", type=int, default=838)
+    ap.add_argument("--patterns", type=int, default=64)
+    ap.add_argument("--method", default="linear_compact")
+    a = ap.parse_args()
+    print(json.dumps(measure(a.pilots, a.patterns, method=a.method)))
