@@ -460,7 +460,7 @@ def measure_leg(job, args, workload, group, steps, warmup, frames=None, patterns
             eng.run_frames(dataset_step(off), seed=seed, frame_offset=off, outputs=names, out=out, check=False)
         elif kind == "fullcov" and nch == 1:
             eng.run_frames(d_first, seed=seed, frame_offset=off, outputs=names, out=out, check=False)
-            eng.mmse_full_apply_pilots(out["h_ls_pilots"], slots[0], W, out=out["H_mmse"], scratch=scr[0])
+            eng.mmse_full_apply_pilots(out["h_ls_pilots"], slots[0], W, out=out["H_mmse"], scratch=scr[0], pads_are_zero=True)
         elif kind == "fullcov":
             main = torch.cuda.current_stream()
             sF.wait_stream(main)                                 # (the previous step has finished with every buffer)
@@ -471,7 +471,7 @@ def measure_leg(job, args, workload, group, steps, warmup, frames=None, patterns
                     e_f = torch.cuda.Event(); e_f.record()
                 with torch.cuda.stream(sG):
                     sG.wait_event(e_f)
-                    eng.mmse_full_filter_pilots(oc["h_ls_pilots"], slots[0], W, scr[c])
+                    eng.mmse_full_filter_pilots(oc["h_ls_pilots"], slots[0], W, scr[c], pads_are_zero=True)
                     e_g = torch.cuda.Event(); e_g.record()
                 with torch.cuda.stream(sI):
                     sI.wait_event(e_g)

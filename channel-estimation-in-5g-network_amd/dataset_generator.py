@@ -257,7 +257,7 @@ class ChannelEstimationDataset:
         # count) float32 records plus the int64 frame indices, gathered to rank 0 (the tensors stay in their rank's files)
         local = np.concatenate(records) if records else np.zeros((0, 8), np.float32)
         local_ids = np.concatenate(frame_ids) if frame_ids else np.zeros(0, np.int64)
-        allrec, allids = _sharding.gather_records(local, local_ids, dst=0, capacity=-(-int(num_samples) // max(1, world)))
+        allrec, allids = _sharding.gather_records(local, local_ids, dst=0, total=int(num_samples))   # capacity from the group's own size
         if allrec is not None:
             tot = allrec[:, 7].sum() if len(allrec) else 1.0
             manifest["summary"] = {"frames_all_ranks": int(len(allrec)),

@@ -522,15 +522,23 @@ class Engine:
             torch.cuda.current_stream(self.device).synchronize()   # our scratch is freed on return
         return out
 
-    def mmse_full_apply_pilots(self, h_ls_pilots, slot, W, out=None, scratch=None):
+    def _zero_pads(self, h, P, pads_are_zero):
+        """The GEMM may read rows of ``h_ls_pilots`` in place, pad columns P .. stride - 1 included (chest.h: they must be 0; a NaN
+        there would poison whole output rows).  ``run_frames`` writes them as zeros; for any other tensor they are zeroed here."""
+        if not pads_are_zero and h.shape[2] > P:
+            h[:, :, P:].zero_()
+
+    def mmse_full_apply_pilots(self, h_ls_pilots, slot, W, out=None, scratch=None, pads_are_zero=False):
         """Full-covariance MMSE for frames produced by ``run_frames(..., outputs=[..., "h_ls_pilots"])``: one right-hand
         side per (frame, rx) instead of per (frame, rx, tx) -- the reference's callers repeat rx over tx, so the T grids of
-        an rx antenna are identical -- and every result written T times.  Returns H_mmse [B,S,R,T,nsc]."""
+        an rx antenna are identical -- and every result written T times.  Returns H_mmse [B,S,R,T,nsc].  The pad entries
+        ``h_ls_pilots[:, :, P:]`` are zeroed in place unless ``pads_are_zero`` vouches for them (run_frames' own output)."""
         g = self.geom
         h = self._c64(h_ls_pilots)
         P = self.num_pilots(slot)
         if h.dim() != 3 or h.shape[1] != g.num_rx or h.shape[2] < P:
             raise ValueError(f"h_ls_pilots must be [B, {g.num_rx}, >= {P}]")
+        self._zero_pads(h, P, pads_are_zero)
         if tuple(W.shape) != (P, P):
             raise ValueError(f"W must be [{P}, {P}] for this pattern")
         B = h.shape[0]
@@ -552,7 +560,7 @@ class Engine:
             torch.cuda.current_stream(self.device).synchronize()   # our scratch is freed on return
         return out
 
-    def mmse_full_filter_pilots(self, h_ls_pilots, slot, W, scratch):
+    def mmse_full_filter_pilots(self, h_ls_pilots, slot, W, scratch, pads_are_zero=False):
         """Stage 1 of ``mmse_full_apply_pilots`` on the current stream: W h_ls for every (frame, rx) on the MFMA pipe; the
         filtered pilot values stay in ``scratch`` (``mmse_full_scratch(slot, B * R)``, one per batch in flight)."""
         g = self.geom
@@ -560,6 +568,7 @@ class Engine:
         P = self.num_pilots(slot)
         if h.dim() != 3 or h.shape[1] != g.num_rx or h.shape[2] < P or not h.is_contiguous():
             raise ValueError(f"h_ls_pilots must be a contiguous [B, {g.num_rx}, >= {P}] tensor")
+        self._zero_pads(h, P, pads_are_zero)
         if tuple(W.shape) != (P, P) or not W.is_contiguous():
             raise ValueError(f"W must be a contiguous [{P}, {P}] tensor for this pattern")
         B = h.shape[0]

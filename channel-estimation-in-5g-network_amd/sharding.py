@@ -42,15 +42,17 @@ def frame_choices(seed: int, frame_index: np.ndarray, num_options):
 
 
 def gather_records(local: "np.ndarray", frame_index: "np.ndarray" = None, dst: int = 0, all_ranks: bool = False, group=None,
-                   capacity: int = None, force_collective: bool = False):
+                   capacity: int = None, force_collective: bool = False, total: int = None):
     """The job's single collective: every rank's per-frame records (float32 [n_local, C]) together with their GLOBAL frame
     indices (int64: float32 is exact only below 2^24 frames), concatenated in rank order.
 
     ONE collective carries everything: each rank sends an int32 block [capacity + 1, C + 2] -- row 0 holds its record count,
     the rows after it the float32 records bit-cast to int32 (the transport moves bytes, it does no arithmetic) followed by the
     low and high halves of the frame index.  ``capacity`` is the largest shard size; jobs that shard with ``shard_range``
-    know it without talking (``ceil(total / world)``) and pass it.  Without it the sizes are agreed by one extra 8-byte
-    all-gather first.
+    know it without talking (``ceil(total / world)``): they pass ``total`` (the job's record count; the capacity is then derived
+    from the size of the GROUP the collective runs in) or ``capacity`` itself.  Without either the sizes are agreed by one extra
+    8-byte all-gather first.  A rank holding more than the capacity still enters the collective (sentinel count, no payload) and
+    raises after it, together with every rank that receives the blocks: nobody is left waiting.
 
     Default: a ``gather`` to rank ``dst`` -- ``dst`` is a rank OF ``group`` (the default group: the global rank) -- the
     other ranks get ``(None, None)``.  ``all_ranks=True`` makes it an ``all_gather``.  Works on CPU (gloo) and GPU
@@ -73,17 +75,23 @@ def gather_records(local: "np.ndarray", frame_index: "np.ndarray" = None, dst: i
     backend = dist.get_backend(group)
     dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
     n_local, width = local.shape
+    if capacity is None and total is not None:
+        capacity = -(-int(total) // world)
     if capacity is None:
         n = torch.tensor([n_local], dtype=torch.int64, device=dev)
         sizes = [torch.zeros_like(n) for _ in range(world)]
         dist.all_gather(sizes, n, group=group)                           # 8 bytes per rank, only when the caller cannot say
         capacity = max(int(c.item()) for c in sizes)
-    if n_local > capacity:
-        raise ValueError(f"{n_local} local records exceed the stated capacity {capacity}")
+    # A rank whose records do not fit the stated capacity must NOT raise before the collective (the others would wait in it
+    # until the timeout): it enters with the sentinel count -1 and no payload, and raises after it -- as does every rank that
+    # receives the blocks.  Row 0 also carries the capacity the rank was told, so that ranks disagreeing about it are named.
+    overflow = n_local > capacity
     block = np.zeros((capacity + 1, width + 2), dtype=np.int32)
-    block[0, 0] = n_local
-    block[1:n_local + 1, :width] = np.ascontiguousarray(local).view(np.int32)
-    block[1:n_local + 1, width:] = np.ascontiguousarray(ids).view(np.int32).reshape(-1, 2)     # little endian: low, high
+    block[0, 0] = -1 if overflow else n_local
+    block[0, 1] = capacity
+    if not overflow:
+        block[1:n_local + 1, :width] = np.ascontiguousarray(local).view(np.int32)
+        block[1:n_local + 1, width:] = np.ascontiguousarray(ids).view(np.int32).reshape(-1, 2)     # little endian: low, high
     send = torch.from_numpy(block).to(dev)
     if all_ranks:
         parts = [torch.zeros_like(send) for _ in range(world)]
@@ -94,7 +102,15 @@ def gather_records(local: "np.ndarray", frame_index: "np.ndarray" = None, dst: i
         # torch's gather takes the GLOBAL rank of the destination
         dist.gather(send, parts, dst=dist.get_global_rank(group, dst) if group is not None else dst, group=group)
         if not root:
+            if overflow:
+                raise ValueError(f"{n_local} local records exceed the stated capacity {capacity} (rank {rank})")
             return None, None
+    heads = [p[0, :2].cpu().numpy() for p in parts]
+    bad = [r for r, h in enumerate(heads) if int(h[0]) < 0]
+    if bad:
+        raise ValueError(f"rank(s) {bad} hold more records than the stated capacity {capacity}")
+    if any(int(h[1]) != capacity for h in heads):
+        raise ValueError(f"ranks disagree about the capacity: {[int(h[1]) for h in heads]}")
     recs, idl = [], []
     for p in parts:
         b = p.cpu().numpy()

@@ -341,7 +341,10 @@ int chest_mmse_full_apply(chest_ctx* ctx, void* stream, int32_t num_frames, cons
  * caller of the reference repeats rx over tx (src/dataset_generator.py:63-64), so the R*T grids of a frame hold only R
  * different right-hand sides; this entry point multiplies B*R rows instead of B*R*T and writes each result T times
  * (H_est [B][S][R][T][nsc]) -- identical values, 1/T of the matrix work and no gather from a [B][S][R][T][nsc] input.
- * scratch: chest_mmse_full_apply_scratch_bytes(P, B*R) bytes. */
+ * scratch: chest_mmse_full_apply_scratch_bytes(P, B*R) bytes.
+ * PRECONDITION (apply_pilots and filter_pilots): the pad entries h_ls_pilots[b][r][P .. h_ls_stride-1] are 0, as
+ * chest_frames_run writes them.  When h_ls_stride is P rounded up to 16, B*R is a multiple of 128 and the pointer is 16-byte
+ * aligned, the GEMM reads the rows in place, pads included: a NaN / Inf there would poison the whole output row. */
 int chest_mmse_full_apply_pilots(chest_ctx* ctx, void* stream, int32_t num_frames, const float* h_ls_pilots,
                                  int32_t h_ls_stride, int32_t pattern_slot, const float* W, float* h_scratch, float* H_est);
 /* Its two stages on their own -- filter: pack + W h_ls on the MFMA pipe, the filtered pilot values stay in h_scratch; interp:

@@ -318,3 +318,25 @@ def test_per_frame_status_marks_only_the_bad_frames_and_the_batch_continues():
     okf = st == 0
     assert torch.equal(out["rx"][okf], clean["rx"][okf]) and torch.equal(out["H_ls"][okf], clean["H_ls"][okf])
     assert float(out["rx"][~okf].abs().max()) == 0.0                   # failed frames leave their outputs untouched
+
+
+def test_full_covariance_apply_ignores_garbage_in_the_pad_columns():
+    """with h_ls_stride == P padded to 16 and B * R a multiple of 128 the GEMM reads the caller's h_ls_pilots in place,
+    pad columns included (chest.h: they must be 0).  The engine zeroes the pads of tensors it did not produce: NaN in the pad of a
+    hand-made tensor must not reach the result (32 frames x 4 rx = 128 rows: the in-place route)."""
+    geom = E.Geometry(fft_size=1024, cp_length=72, num_symbols=14, useful_subcarriers=72, num_tx=4, num_rx=4)
+    eng = E.Engine(geom, 0)
+    rs = np.random.RandomState(77)
+    P = 99                                                                # padded to 112: 13 pad columns
+    pil = np.sort(rs.permutation(geom.grid)[:P])
+    slot = eng.pattern_slot(pil, "linear")
+    A = rs.randn(P, P) + 1j * rs.randn(P, P)
+    W = eng.mmse_full_prepare(A @ A.conj().T / P + np.eye(P), 10.0)
+    good = eng.run_frames(E.make_descs("EVA", 70.0, 10.0, slot, n=32), seed=5, outputs=("h_ls_pilots",))["h_ls_pilots"]
+    assert good.shape[2] == 112 and good.shape[0] * good.shape[1] == 128
+    want = eng.mmse_full_apply_pilots(good, slot, W, pads_are_zero=True)
+    dirty = good.clone()
+    dirty[:, :, P:] = float("nan")
+    got = eng.mmse_full_apply_pilots(dirty, slot, W)
+    assert torch.isfinite(torch.view_as_real(got)).all() and torch.equal(got, want)
+    eng.close()

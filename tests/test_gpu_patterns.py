@@ -420,3 +420,26 @@ def test_structured_and_tiny_patterns_triangulate_validly(U):
             assert cnt[j] == len(ref.simplices)
             A, pi, pw = _plan_matrix(eng, int(slots[j]), len(p))
             assert np.array_equal(A.sum(1) > 0.5, sx >= 0), "hull membership differs"
+
+
+@pytest.mark.parametrize("P", [838, 419])
+def test_device_plan_divergence_from_griddata_is_measured_and_bounded(P):
+    """The batch path's relaxation, as a NUMBER: 64 device-drawn patterns, the same frames (identical tx / H / rx, checked bit for
+    bit) once through the device triangulator's compact plans and once through plans located in Qhull's simplices -- the
+    triangulation griddata('linear') uses (src/baseline_estimators.py:65-79).  Inside co-circular lattice polygons the two valid
+    Delaunay triangulations interpolate differently: a few per cent of the resource elements differ by more than north_star's
+    1e-5, the LS estimate by a few per cent in relative L2, a frame's LS MSE by ~1e-3 relative (no bias: the batch MSE agrees to
+    ~1e-4).  bench.py reports the same record as `per_frame_patterns.plan_parity`; the shared-pattern headline runs on Qhull plans
+    and has no such term."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import plan_parity
+    r = plan_parity.measure(P=P, patterns=64)
+    print(r)
+    assert r["patterns"] >= 50 and 0.85 < r["shared_triangles"] < 1.0
+    assert 0.0 < r["H_ls"]["re_frac_gt_1e5"] < 0.05                 # measured 0.02-0.03
+    assert r["H_ls"]["rel_l2"] < 0.05                               # measured 0.026-0.03
+    assert r["H_mmse"]["re_frac_gt_1e5"] < 0.05 and r["H_mmse"]["rel_l2"] < 0.05
+    assert r["mse_rel_delta_ls"]["mean"] < 3e-3 and r["mse_rel_delta_ls"]["max"] < 2e-2
+    assert r["mse_rel_delta_ls"]["batch"] < 1e-3                    # and it does not bias the batch statistic

@@ -56,6 +56,16 @@ def _worker(rank, world, port, total, q):
                 assert i3.tolist() == [100, 200, 201, 300, 301, 302]
             else:
                 assert r3 is None and i3 is None
+    # a rank holding more than the stated capacity: nobody hangs in the collective; the offender and the root raise after it
+    try:
+        S_.gather_records(np.zeros((3 if rank == world - 1 else 1, 1), np.float32), dst=0, capacity=2)
+        raised = False
+    except ValueError:
+        raised = True
+    assert raised == (rank in (0, world - 1))
+    # `total` instead of `capacity`: derived from the group's own size
+    r4, _ = S_.gather_records(np.full((e - b, 1), float(rank), np.float32), dst=0, total=total)
+    assert (r4 is None) == (rank != 0) and (rank != 0 or len(r4) == total)
     rec2, ids2 = S_.gather_records(_records(b, e)[:, :2], OFFSET + np.arange(b, e, dtype=np.int64), all_ranks=True)
     assert ids2.dtype == np.int64 and ids2.tolist() == list(range(OFFSET, OFFSET + total)) and rec2.shape == (total, 2)
     import torch
