@@ -427,6 +427,8 @@ int chest_profile_read(chest_ctx* ctx, float* taps_ms, float* frame_ms, int32_t*
 int chest_tune(chest_ctx* ctx, const char* key, int32_t value) {
     if (!ctx || !key) { set_error("chest_tune: null argument"); return CHEST_EINVAL; }
     if (strcmp(key, "frame_rx_group") == 0) { ctx->tune_rx_group = value; return CHEST_OK; }
+    if (strcmp(key, "frame_store_extra") == 0) { ctx->tune_store_extra = (value >= -1 && value <= 4) ? value : 0; return CHEST_OK; }
+    if (strcmp(key, "frame_store_waves") == 0) { ctx->tune_store_waves = (value >= 0 && value <= 16) ? value : 0; return CHEST_OK; }
     if (strcmp(key, "frame_min_waves") == 0) { ctx->tune_min_waves = value; return CHEST_OK; }
     if (strcmp(key, "taps_threads") == 0) { ctx->tune_taps_threads = (value == 64 || value == 128 || value == 256) ? value : 0; return CHEST_OK; }
     if (strcmp(key, "pattern_extra_lds") == 0) { ctx->tune_pattern_extra_lds = value < 0 ? 0 : value; return CHEST_OK; }

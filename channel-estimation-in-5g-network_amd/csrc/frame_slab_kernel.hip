@@ -98,7 +98,7 @@ struct SlabArgs {
     float* alpha;
     float2* slab;      // LDS, 16-B aligned
     RngKey key;
-    int b, RG;
+    int b, RG, nst, nsx;    // nsx: dedicated store waves at the end of the workgroup; nst: store-out crew override (chest_tune "frame_store_waves", experiments), 0 = by the rule in slab_body
 };
 
 // LDS slab segment capacities in float2 elements (even, +2 so that a parity shift of one element fits)
@@ -130,10 +130,17 @@ __device__ __forceinline__ void slab_body(const SlabArgs& A) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // subcarrier pairs are dealt evenly to the waves (599 subcarriers: 60 pairs on each of 5 waves) so that no wave of
     // the workgroup is the straggler at the unit barriers
+    // Dedicated store waves (A.nsx > 0): the LAST nsx waves of the workgroup own no subcarriers -- they take no part in the
+    // synthesis and do nothing but stream finished slabs to HBM, while the compute waves go from the "slab complete" barrier
+    // straight into the next unit's synthesis: the store-out of unit u runs beside the compute stretch of unit u + 1 for EVERY
+    // compute wave (the excused-wave scheme below gives that head start to one or two waves only).
+    const int nsx = A.nsx;
+    const int ncw = nwave - nsx;                                 // compute waves
+    const bool cw = wave < ncw;                                  // wave-uniform
     const int npair = (nsc + 1) >> 1;
-    const int ppw = (npair + nwave - 1) / nwave;
+    const int ppw = (npair + ncw - 1) / ncw;
     const int pr = wave * ppw + lane;
-    const bool act = lane < ppw && pr < npair;
+    const bool act = cw && lane < ppw && pr < npair;
     const int k0 = 2 * pr, k1 = k0 + 1;
     const bool v1 = act && k1 < nsc;
     const bool tailw = __builtin_amdgcn_readfirstlane((int)((nsc & 1) && wave == (npair - 1) / ppw));   // the wave that owns the odd last subcarrier
@@ -192,11 +199,18 @@ __device__ __forceinline__ void slab_body(const SlabArgs& A) {
     // Store-out crew.  A workgroup of 4n+1 waves puts two of its waves on one SIMD; the younger of them loses the issue
     // arbitration and is the straggler of every compute stretch (stamps: +40 % on the 5th wave).  It is excused from the
     // store-out: after the "slab complete" barrier it goes straight to the next unit's compute while the others stream the
-    // slab, which hands it a head start the length of the store-out.
-    // (Only where a unit carries enough synthesis for that to pay: with one or two rows per unit the stores are the
-    // longer leg and every wave is needed for them.)
-    const int nstw = (nwave > 4 && (nwave & 3) == 1 && RG * T >= 4) ? nwave - 1 : nwave;
-    const bool storer = wave < nstw;
+    // slab, which hands it a head start the length of the store-out.  4n + 2 waves -- the 10-wave workgroups of the 2048-FFT
+    // grids -- leave TWO SIMDs with an extra wave: both are excused.  Measured per crew size (tools/ab_store_waves.py,
+    // profiles/r04_store_crew.txt): 2048-FFT 4x4 2.09 ms with all ten waves storing, 2.01-2.04 with four to eight; 2x2 2.07 -> 1.98;
+    // SISO (two symbols per unit since round 2) 0.83 -> 0.76: the rule holds for every staged shape.  Units of one or two rows
+    // (the generic instantiations at T = R = 1) keep every wave on the stores.
+    const int xw = nwave & 3;
+    // (ten waves and one workgroup per CU: the store-out of a unit has nothing else to hide behind; four storing waves, six in the
+    // next unit's synthesis measure 1-4 % below eight / two)
+    const int nst_rule = (nwave > 4 && (xw == 1 || xw == 2) && RG * T * SSN >= 2) ? (nwave >= 10 ? 4 : nwave - xw) : nwave;
+    const int nstw = nsx > 0 ? nsx : (A.nst > 0 ? min(A.nst, nwave) : nst_rule);
+    const bool storer = nsx > 0 ? !cw : wave < nstw;
+    const int swave = nsx > 0 ? wave - ncw : wave;               // my index in the store crew
     STAMP_DECL;
     STAMP(st_a);
 
@@ -219,6 +233,9 @@ __device__ __forceinline__ void slab_body(const SlabArgs& A) {
         float2 xs[SSN][2];
         bool pp[SSN][2];
 #pragma unroll
+        for (int ss = 0; ss < SSN; ++ss) { sc[ss][0] = sc[ss][1] = 0; xs[ss][0] = xs[ss][1] = make_float2(0.f, 0.f); pp[ss][0] = pp[ss][1] = false; }
+        if (cw) {
+#pragma unroll
         for (int ss = 0; ss < SSN; ++ss) {
             if constexpr (INJ) {
                 sc[ss][0] = sln[ss][0]; sc[ss][1] = sln[ss][1];
@@ -239,6 +256,7 @@ __device__ __forceinline__ void slab_body(const SlabArgs& A) {
             xs[ss][1] = cis_unit(__builtin_amdgcn_fractf(u1));
             pp[ss][0] = act && ss < ns && sc[ss][0] < (unsigned)P; pp[ss][1] = v1 && ss < ns && sc[ss][1] < (unsigned)P;
         }
+        }
         for (int rg = 0; rg < ngroups; ++rg) {
             const int r0 = rg * RG;
             // global spans of this unit (element offsets inside the frame) and their parities
@@ -251,6 +269,7 @@ __device__ __forceinline__ void slab_body(const SlabArgs& A) {
                 // compute the whole unit into registers first: nothing here touches the slab, so this stretch overlaps the
                 // other waves' store-out of the previous unit
                 float2 hv[SSN][RGT * TT][2], qv[SSN][RGT][2];
+                if (cw) {
 #pragma unroll
                 for (int ss = 0; ss < SSN; ++ss) {
                     if (ss >= ns) continue;
@@ -294,6 +313,7 @@ __device__ __forceinline__ void slab_body(const SlabArgs& A) {
                         qv[ss][rr][1] = make_float2(fmaf(noise_std, n1v.x, y1.x), fmaf(noise_std, n1v.y, y1.y));
                     }
                 }
+                }
                 STAMP_ADD(0);                                                    // W compute
                 if (!first_unit) __syncthreads();                                // previous unit's store-out has read the slab
                 first_unit = false;
@@ -330,7 +350,7 @@ __device__ __forceinline__ void slab_body(const SlabArgs& A) {
                 if (act && rg == 0 && txb != nullptr) {
                     for (int t = 0; t < T; ++t) put(l_tx + t * nsc, x0, x1);
                 }
-                for (int rr = 0; rr < RG; ++rr) {
+                for (int rr = 0; cw && rr < RG; ++rr) {
                     const int r = r0 + rr;
                     float2 hs0 = make_float2(0.f, 0.f), hs1 = make_float2(0.f, 0.f);
                     for (int t = 0; t < T; ++t) {
@@ -367,7 +387,7 @@ __device__ __forceinline__ void slab_body(const SlabArgs& A) {
             __syncthreads();                                                     // slab complete
             STAMP_ADD(3);                                                        // W barrier A
             if (storer) {
-                int ph = wave;                                                   // rotate the stores of consecutive segments over the waves
+                int ph = swave;                                                  // rotate the stores of consecutive segments over the waves
                 if (rg == 0 && txb != nullptr) { const int n = seg_store(txb + e_tx, l_tx, ns * T * nsc, ph, nstw); ph = (ph + nstw - n % nstw) % nstw; }
                 if (Hb != nullptr) { const int n = seg_store(Hb + e_h, l_h, ns * RG * T * nsc, ph, nstw); ph = (ph + nstw - n % nstw) % nstw; }
                 if (rxb != nullptr) seg_store(rxb + e_rx, l_rx, ns * RG * nsc, ph, nstw);
@@ -439,6 +459,9 @@ __device__ __forceinline__ void slab_body(const SlabArgs& A) {
     const gptr_u16 triof = (gptr_u16)((const CHEST_GLOBAL unsigned char*)pat.plan + (CP ? pat.pad : 0));
     uint32_t idn[SSN][2];
 #pragma unroll
+    for (int ss = 0; ss < SSN; ++ss) { cn[ss][0] = cn[ss][1] = PlanRec{0.f, 0.f, 0u, 0u}; idn[ss][0] = idn[ss][1] = 0; }
+    if (cw) {
+#pragma unroll
     for (int ss = 0; ss < SSN; ++ss) {
         const int sy = ss < S ? ss : S - 1;
         if constexpr (CP) {
@@ -450,6 +473,7 @@ __device__ __forceinline__ void slab_body(const SlabArgs& A) {
             idn[ss][0] = idn[ss][1] = 0;
         }
     }
+    }
     first_unit = true;
     // STAGED: a unit's estimates are gathered into registers one unit AHEAD, between the "slab complete" barrier of the unit
     // before and that unit's store-out -- the plan records they need were requested a barrier pair earlier and no store sits
@@ -457,7 +481,12 @@ __device__ __forceinline__ void slab_body(const SlabArgs& A) {
     // wave's stores).
     constexpr int EVR = STAGED ? RGT : 1;
     float2 ev[SSN][EVR][2];
+#pragma unroll
+    for (int ss = 0; ss < SSN; ++ss)
+#pragma unroll
+        for (int rr = 0; rr < EVR; ++rr) ev[ss][rr][0] = ev[ss][rr][1] = make_float2(0.f, 0.f);
     auto gather = [&](const PlanRec (&c)[SSN][2], int s0, int r0, float2 (&e)[SSN][EVR][2]) {   // c: records of symbols s0, s0 + 1, ...
+        if (!cw) return;                                                         // (store waves hold no elements)
 #pragma unroll
         for (int ss = 0; ss < SSN; ++ss) {
             const PlanRec c0 = plan_rec<CP>(c[ss][0], s0 + ss, kc0), c1 = plan_rec<CP>(c[ss][1], s0 + ss, kc1);
@@ -474,7 +503,7 @@ __device__ __forceinline__ void slab_body(const SlabArgs& A) {
         for (int ss = 0; ss < SSN; ++ss) {
             cc[ss][0] = cn[ss][0]; cc[ss][1] = cn[ss][1];
             const int sn = sb + SSN + ss;
-            if (sn < S) {
+            if (cw && sn < S) {
                 if constexpr (CP) {
                     cn[ss][0] = ld_plan(plan, idn[ss][0]); cn[ss][1] = ld_plan(plan, idn[ss][1]);
                     const int s2 = sn + SSN;
@@ -488,7 +517,7 @@ __device__ __forceinline__ void slab_body(const SlabArgs& A) {
             float2* __restrict__ l_l = slab + seg_l + ((par_h + e_h) & 1);
             float2* __restrict__ l_m = slab + seg_m + ((par_h + e_h) & 1);
             const bool more = rg + 1 < ngroups || sb + SSN < S;                  // another unit follows (uniform)
-            if (want_metrics) {
+            if (want_metrics && cw) {
                 // sum_t |H_t - v|^2 = sum_t |H_t - Hbar|^2 + T |Hbar - v|^2 ; the first term is
                 // estimate-independent and comes analytically from K1 (ST_SUM_VAR).
 #pragma unroll
@@ -555,7 +584,7 @@ __device__ __forceinline__ void slab_body(const SlabArgs& A) {
                 if (more) { if (rg + 1 < ngroups) gather(cc, sb, r0 + RG, ev); else gather(cn, sb + SSN, 0, ev); }
             }
             if (storer) {
-                int ph = wave;
+                int ph = swave;
                 if (Lb != nullptr) { const int n = seg_store(Lb + e_h, l_l, ns * RG * T * nsc, ph, nstw); ph = (ph + nstw - n % nstw) % nstw; }
                 if (Mb != nullptr) seg_store(Mb + e_h, l_m, ns * RG * T * nsc, ph, nstw);
             }
@@ -584,7 +613,8 @@ __device__ __forceinline__ void slab_body(const SlabArgs& A) {
     }
 }
 
-// MAXTHR: largest workgroup this instantiation is launched with (320 = 5 waves covers nsc <= 640, the 1024-FFT grids).
+// MAXTHR: largest workgroup this instantiation is launched with (448 = 5 compute waves for nsc <= 640, the 1024-FFT grids, and up
+// to two store waves; 768 = 10 + 2 for the 2048-FFT grids).
 template <int MAXTHR, int MINW, int TT, int RR, int RGT, int SS, bool INJ, bool CP>
 __global__ void __launch_bounds__(MAXTHR, MINW)
 frame_slab_kernel(const FrameParams* __restrict__ fpp, const chest_frame_desc* __restrict__ descs,
@@ -682,7 +712,7 @@ frame_slab_kernel(const FrameParams* __restrict__ fpp, const chest_frame_desc* _
     A.slab = (float2*)(A.alpha + 8);                             // 16-B aligned: hp span is a multiple of 16 B, 40 floats = 160 B
     const uint64_t frame = frame_offset + (uint64_t)b;
     A.key = RngKey{(uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)frame, (uint32_t)(frame >> 32)};
-    A.b = b; A.RG = RG;
+    A.b = b; A.RG = RG & 0xFF; A.nst = (RG >> 8) & 0xFF; A.nsx = RG >> 16;
     switch (A.prof->ntaps) {                                     // workgroup-uniform dispatch on the profile
         case 5: slab_body<5, TT, RR, RGT, SS, INJ, CP>(A); break;         // EPA at 15.36 MHz
         case 8: slab_body<8, TT, RR, RGT, SS, INJ, CP>(A); break;         // EVA
@@ -738,6 +768,14 @@ int launch_k2_slab(chest_ctx* ctx, hipStream_t st, int32_t B, const chest_frame_
     const int npair = (fp.nsc + 1) / 2, nwave = (npair + 63) / 64;
     if (nwave > 16) { set_error("frame kernel handles at most 2047 used subcarriers (got %d)", fp.nsc); return CHEST_EINVAL; }
     const int RG = choose_rx_group(ctx, Pmax);
+    // dedicated store waves per workgroup (slab_body): two for the 4x4 frames of the 1024-FFT grids (five compute waves at 128
+    // VGPRs, two workgroups per CU: 4.51 -> 4.32 ms per 6 250 frames; one extra wave is always slower -- six or eleven waves sit
+    // unevenly on four SIMDs -- and 2x2 frames lose 3 % with two: profiles/r04_store_crew.txt); chest_tune "frame_store_extra"
+    // overrides (-1 = none)
+    int nsx = ctx->tune_store_extra != 0 ? (ctx->tune_store_extra < 0 ? 0 : ctx->tune_store_extra) : ((fp.T * fp.R >= 16 && nwave <= 5) ? 2 : 0);
+    if (nsx > 2) nsx = 2;                                       // (the instantiations' launch bounds leave room for two)
+    if (nwave + nsx > 16) nsx = 0;
+    const int RGarg = RG | (ctx->tune_store_waves << 8) | (nsx << 16);   // (crew parameters ride in the high bits of the kernel argument)
     const int T = fp.T, R = fp.R;
     const bool injected = inj.u_sym || inj.u_angle || inj.n_re;         // parity / replay mode: the generic instantiations
     // SISO frames have three rows per symbol: two symbols per unit halve the per-unit synchronisation (the spans of
@@ -749,35 +787,35 @@ int launch_k2_slab(chest_ctx* ctx, hipStream_t st, int32_t B, const chest_frame_
     const bool siso = !injected && !(fp.half & 1) && nwave <= 5 && T == 1 && R == 1 && RG == 1;
     const size_t lds = slab_lds_bytes(fp.nsc, fp.T, fp.R, RG, Pmax, siso ? SS_SISO : 1);
     if (lds > 160 * 1024) { set_error("frame kernel needs %zu B of LDS (> 160 KiB): too many antennas, subcarriers or pilots", lds); return CHEST_EINVAL; }
-    const dim3 grid((unsigned)B), block((unsigned)nwave * 64);
-#define CHEST_SLAB_ARGS st, grid, block, lds, descs, Pmax, seed, frame_offset, inj, out, workspace, RG
+    const dim3 grid((unsigned)B), block((unsigned)(nwave + nsx) * 64);
+#define CHEST_SLAB_ARGS st, grid, block, lds, descs, Pmax, seed, frame_offset, inj, out, workspace, RGarg
     if (compact) {
         // compact plans (chest_patterns_build method 2; every frame of the launch must use one -- the kernel flags a frame whose
         // pattern is in the other format): the device-RNG instantiations of the 1024-FFT grids and the generic one
         if (nwave > 5) { set_error("compact interpolation plans are read by the frame kernels of grids up to 640 used subcarriers (got %d)", fp.nsc); return CHEST_EINVAL; }
         if (!injected && !(fp.half & 1)) {
-            if (T == 2 && R == 2 && RG == 2) return launch_one<320, 5, 2, 2, 2, 1, false, true>(ctx, LDS_FRAME_CP, CHEST_SLAB_ARGS);
-            if (T == 4 && R == 4 && RG == 1) return launch_one<320, 4, 4, 4, 1, 1, false, true>(ctx, LDS_FRAME_44_CP, CHEST_SLAB_ARGS);
-            if (siso) return launch_one<320, 5, 1, 1, 1, SS_SISO, false, true>(ctx, LDS_FRAME_11_CP, CHEST_SLAB_ARGS);
+            if (T == 2 && R == 2 && RG == 2) return launch_one<448, 5, 2, 2, 2, 1, false, true>(ctx, LDS_FRAME_CP, CHEST_SLAB_ARGS);
+            if (T == 4 && R == 4 && RG == 1) return launch_one<448, 4, 4, 4, 1, 1, false, true>(ctx, LDS_FRAME_44_CP, CHEST_SLAB_ARGS);
+            if (siso) return launch_one<448, 5, 1, 1, 1, SS_SISO, false, true>(ctx, LDS_FRAME_11_CP, CHEST_SLAB_ARGS);
         }
-        return launch_one<320, 4, 0, 0, 0, 1, true, true>(ctx, LDS_FRAME_GEN_CP, CHEST_SLAB_ARGS);
+        return launch_one<448, 4, 0, 0, 0, 1, true, true>(ctx, LDS_FRAME_GEN_CP, CHEST_SLAB_ARGS);
     }
     if (nwave <= 5) {                      // the 1024-FFT grids (nsc <= 640): specialised antenna counts on the device-RNG path
         if (!injected) {
-            if (fp.half & 1) return launch_one<320, 4, 0, 0, 0, 1, true>(ctx, LDS_FRAME_GEN, CHEST_SLAB_ARGS);   // a pair straddles DC
+            if (fp.half & 1) return launch_one<448, 4, 0, 0, 0, 1, true>(ctx, LDS_FRAME_GEN, CHEST_SLAB_ARGS);   // a pair straddles DC
             // 2x2: 96 VGPRs (five waves per SIMD) so that THREE 5-wave workgroups are resident per CU -- at 128 VGPRs only two
             // are placed although 15 waves would fit; 2.00 against 2.33 ms per 10 000 frames (chest_tune "frame_min_waves" = 4
             // selects the 128-VGPR instantiation for A/B)
-            if (T == 2 && R == 2 && RG == 2 && ctx->tune_min_waves == 4) return launch_one<320, 4, 2, 2, 2, 1, false>(ctx, LDS_FRAME_W5, CHEST_SLAB_ARGS);
-            if (T == 2 && R == 2 && RG == 2) return launch_one<320, 5, 2, 2, 2, 1, false>(ctx, LDS_FRAME, CHEST_SLAB_ARGS);
-            if (T == 4 && R == 4 && RG == 1) return launch_one<320, 4, 4, 4, 1, 1, false>(ctx, LDS_FRAME_44, CHEST_SLAB_ARGS);
-            if (siso) return launch_one<320, 5, 1, 1, 1, SS_SISO, false>(ctx, LDS_FRAME_11, CHEST_SLAB_ARGS);
+            if (T == 2 && R == 2 && RG == 2 && ctx->tune_min_waves == 4) return launch_one<448, 4, 2, 2, 2, 1, false>(ctx, LDS_FRAME_W5, CHEST_SLAB_ARGS);
+            if (T == 2 && R == 2 && RG == 2) return launch_one<448, 5, 2, 2, 2, 1, false>(ctx, LDS_FRAME, CHEST_SLAB_ARGS);
+            if (T == 4 && R == 4 && RG == 1) return launch_one<448, 4, 4, 4, 1, 1, false>(ctx, LDS_FRAME_44, CHEST_SLAB_ARGS);
+            if (siso) return launch_one<448, 5, 1, 1, 1, SS_SISO, false>(ctx, LDS_FRAME_11, CHEST_SLAB_ARGS);
         }
-        return launch_one<320, 4, 0, 0, 0, 1, true>(ctx, LDS_FRAME_GEN, CHEST_SLAB_ARGS);
+        return launch_one<448, 4, 0, 0, 0, 1, true>(ctx, LDS_FRAME_GEN, CHEST_SLAB_ARGS);
     }
     if (nwave <= 10) {                     // the 2048-FFT grids (nsc <= 1280)
-        if (!injected && !(fp.half & 1) && T == 4 && R == 4 && RG == 1) return launch_one<640, 3, 4, 4, 1, 1, false>(ctx, LDS_FRAME_640_44, CHEST_SLAB_ARGS);
-        return launch_one<640, 3, 0, 0, 0, 1, true>(ctx, LDS_FRAME_640, CHEST_SLAB_ARGS);
+        if (!injected && !(fp.half & 1) && T == 4 && R == 4 && RG == 1) return launch_one<768, 3, 4, 4, 1, 1, false>(ctx, LDS_FRAME_640_44, CHEST_SLAB_ARGS);
+        return launch_one<768, 3, 0, 0, 0, 1, true>(ctx, LDS_FRAME_640, CHEST_SLAB_ARGS);
     }
     return launch_one<1024, 4, 0, 0, 0, 1, true>(ctx, LDS_FRAME_1024, CHEST_SLAB_ARGS);
 #undef CHEST_SLAB_ARGS

@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""Store-out crew of the frame kernel (chest_tune "frame_store_waves"): how many of a workgroup's waves stream a unit's slab to
+HBM while the others go straight to the next unit's synthesis.  Frame kernel time (library HIP events) per crew size for the
+2048-FFT 4x4 shape (10 waves, one workgroup per CU), the 1024-FFT 4x4, 2x2 and SISO shapes (5 waves); one process, crews
+interleaved, the same output buffers.  GPU only."""
+import importlib, os, sys
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+E = importlib.import_module("channel-estimation-in-5g-network_amd.engine")
+KNOB = sys.argv[1] if len(sys.argv) > 1 else "frame_store_waves"      # or "frame_store_extra": dedicated store waves (-1 = none)
+ALL = ("tx", "rx", "H", "H_ls", "H_mmse", "pilot_symbols", "pilot_mask")
+SHAPES = ((4, 4, "ETU", 555.6, 2304, 2048, 144, 1200, ("tx", "rx", "H", "pilot_symbols", "pilot_mask", "h_ls_pilots"), (0, 10, 9, 8, 7, 6, 5, 4)),
+          (4, 4, "ETU", 370.4, 6250, 1024, 72, 600, ALL, (0, 5, 4, 3, 2)), (2, 2, "EVA", 111.1, 10000, 1024, 72, 600, ALL, (0, 5, 4, 3, 2)),
+          (1, 1, "EPA", 5.56, 10000, 1024, 72, 600, ALL, (0, 5, 4, 3, 2, 1)))
+for T, R, ct, fd, F, fft, cp, U, names, crews in SHAPES:
+    if KNOB == "frame_store_extra":
+        crews = (-1, 1, 2)
+    geom = E.Geometry(fft_size=fft, cp_length=cp, useful_subcarriers=U, num_tx=T, num_rx=R)
+    eng = E.Engine(geom, 0)
+    slots = eng.build_patterns(0, [geom.grid // 10] * 4, seed=1, pattern_ids=np.arange(4, dtype=np.uint64), method="linear")
+    d = torch.from_numpy(E.make_descs(ct, fd, 10.0, slots[np.arange(F) % 4], n=F).view(np.uint8).copy()).to(eng.device)
+    out = eng.run_frames(d, seed=3, outputs=names)
+    ref = {k: out[k].clone() for k in names}
+    res = {c: [] for c in crews}
+    for it in range(5):
+        for c in crews:
+            eng.tune(KNOB, c)
+            eng.profile_begin(1)
+            eng.run_frames(d, seed=3, frame_offset=0, outputs=names, out=out, check=False)
+            res[c].append(eng.profile_read()[1])
+            if it == 0:
+                for k in names:      # (H_mmse: the shrinkage factor is a workgroup sum whose order follows the workgroup size)
+                    if k == "H_mmse":
+                        assert float((ref[k] - out[k]).abs().max()) < 2e-6 * float(ref[k].abs().max()), (c, k)
+                    else:
+                        assert torch.equal(ref[k], out[k]), (c, k)
+    eng.tune(KNOB, 0)
+    eng.check_status()
+    eng.close()
+    print(f"{T}x{R} {fft}-FFT {F} frames, frame kernel ms by {KNOB} (0 = built-in rule): " +
+          "  ".join(f"{c}: {np.median(v[1:]):.3f}" for c, v in res.items()), flush=True)
