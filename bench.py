@@ -149,7 +149,17 @@ def cpu_baseline(workload, budget_s=20.0):
     dt = time.time() - t0
     frames = per_proc * cores
     mse_ls = float(np.mean([p[1] for p in parts])); mse_mm = float(np.mean([p[2] for p in parts]))
-    return {"value": frames / dt, "unit": "frames/s", "cores": cores, "kind": "port",
+    # calibration against the reference itself (tools/ref_ratio.py, run in the build container where the reference is importable;
+    # BASELINE.md 3): seconds per frame of the reference / of this faithful oracle, same machine, one thread, config 2
+    ratio = None
+    try:
+        cal = json.load(open(os.path.join(ROOT, "profiles", "cpu_ref_ratio.json")))
+        ratio = {"ref_ratio": cal["ref_ratio"], "reference_equivalent": frames / dt / cal["ref_ratio"],
+                 "ref_ratio_source": "profiles/cpu_ref_ratio.json (tools/ref_ratio.py: reference %.3f s/frame, oracle faithful %.3f s/frame, "
+                                     "1 thread, build container, %s)" % (cal["reference_s_per_frame"], cal["oracle_faithful_s_per_frame"], cal["workload"])}
+    except Exception:
+        pass
+    return {"value": frames / dt, "unit": "frames/s", "cores": cores, "kind": "port", **(ratio or {"ref_ratio": None}),
             "est_mse": {"ls": mse_ls, "mmse": mse_mm, "frames": frames},        # same statistic as the GPU line's est_mse, other random frames
             "sample": f"{frames} frames of {workload} ({per_proc}/process x {cores} processes), oracle faithful mode "
                       f"(float64 NumPy/SciPy restatement with the reference's cost structure), {dt:.1f} s wall"}

@@ -36,13 +36,75 @@ def chest_rows(src, dst, keep=("chest::",)):
     return rows
 
 
+def timed_region_stats(trace_csv, bench_json, out_csv):
+    """Per-kernel average duration over the launches of the TIMED region only.  rocprofv3's own --stats averages every launch of a
+    kernel name in the process -- the allocation launch, the untimed metrics-only launch (5.9 MB written instead of 10.9 GB) and the
+    warm-up steps included; here the last steps x launches-per-step dispatches of each of the library's kernels are kept, i.e.
+    exactly the full-output launches bench.py timed."""
+    try:
+        b = json.loads([l for l in open(bench_json) if l.startswith("{")][-1])
+    except Exception:
+        return None
+    n_timed = int(b["steps"]) * int(b["config"].get("launches_per_step", 1))
+    per = {}
+    with open(trace_csv) as f:
+        for row in csv.DictReader(f):
+            k = row["Kernel_Name"]
+            if "chest::" in k:
+                per.setdefault(k[:100], []).append((int(row["Start_Timestamp"]), int(row["End_Timestamp"]) - int(row["Start_Timestamp"])))
+    with open(out_csv, "w", newline="") as g:
+        w = csv.writer(g)
+        w.writerow(["# launches of the timed region only (last steps x launches-per-step dispatches per kernel); bench value %.0f frames/s, %.4f ms/step"
+                    % (b["value"], b["ms_per_step"])])
+        w.writerow(["Name", "TimedCalls", "AverageNs", "MinNs", "MaxNs", "AllCallsInProcess"])
+        for k, v in sorted(per.items(), key=lambda kv: -sum(d for _, d in kv[1][-n_timed:])):
+            v.sort()
+            d = [x for _, x in v[-n_timed:]] if len(v) >= n_timed else [x for _, x in v]
+            w.writerow([k, len(d), "%.1f" % (sum(d) / len(d)), min(d), max(d), len(v)])
+    return out_csv
+
+
+def mfma_busy(src, dst, R):
+    """MFMA-pipe busy fraction of cgemm_w_kernel_3m from the counter pass of collect_profiles.sh (part mfma): SQ_VALU_MFMA_BUSY_CYCLES
+    summed over the chip / (1 024 SIMDs x shader cycles), cycles = GRBM_GUI_ACTIVE / 8 (rocprofv3 sums the 8 XCDs)."""
+    cc = newest(os.path.join(src, "pmc_mfma", "**", "*_counter_collection.csv"))
+    if not cc:
+        print("no MFMA counter pass found")
+        return
+    rows = {}
+    for r in csv.DictReader(open(cc)):
+        if "cgemm_w_kernel_3m" in r["Kernel_Name"]:
+            rows.setdefault(r["Dispatch_Id"], {"grid": r["Grid_Size"], "wg": r["Workgroup_Size"],
+                                               "ns": int(r["End_Timestamp"]) - int(r["Start_Timestamp"])})[r["Counter_Name"]] = float(r["Counter_Value"])
+    lines = ["# rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace -- python3 bench.py --workload cfg5_4x4_2048_fullcov --no-cpu-baseline --steps 5 --warmup 2",
+             "# cgemm_w_kernel_3m (W h_ls on v_mfma_f32_32x32x2_f32, 3-multiplication complex product), 2 304 frames = 9 216 right-hand sides, P = 1 678",
+             "# busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8); clock = GRBM_GUI_ACTIVE / 8 / duration",
+             "dispatch  grid  duration_ms  clock_GHz  mfma_busy_cycles  mfma_busy_frac"]
+    fr = []
+    for d, v in sorted(rows.items(), key=lambda kv: int(kv[0])):
+        if "SQ_VALU_MFMA_BUSY_CYCLES" not in v or "GRBM_GUI_ACTIVE" not in v:
+            continue
+        cyc = v["GRBM_GUI_ACTIVE"] / 8.0
+        busy = v["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * cyc)
+        fr.append(busy)
+        lines.append(f"{d}  {v['grid']}  {v['ns'] / 1e6:.4f}  {cyc / v['ns']:.3f}  {v['SQ_VALU_MFMA_BUSY_CYCLES']:.4g}  {busy:.4f}")
+    if fr:
+        lines.append(f"# mean MFMA-pipe busy over {len(fr)} launches: {sum(fr) / len(fr):.4f}  (kernel durations under the counter pass; the bench's own: {R}_bench_cfg5.json)")
+    text = "\n".join(lines) + "\n"
+    open(os.path.join(dst, f"{R}_pmc_mfma_cgemm.txt"), "w").write(text)
+    print(text)
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--round", default="r03")
+    ap.add_argument("--round", default="r04")
+    ap.add_argument("--only-mfma", action="store_true")
     a = ap.parse_args()
     R = a.round
     src, dst = os.path.join(ROOT, "gpurun_out", R), os.path.join(ROOT, "profiles")
-    plain = ["bench_default.json", "bench_cfg2_rccl_one_rank.json", "pmc_pattern_phases_P838.txt", "pmc_pattern_phases_P83.txt", "pmc_sq_pattern_kernel.txt",
+    if a.only_mfma:
+        return mfma_busy(src, dst, R)
+    plain = ["bench_default.json", "store_crew.txt", "plan_parity.txt", "pmc_sq_frame_kernel_cfg5.txt", "bench_cfg2_rccl_one_rank.json", "pmc_pattern_phases_P838.txt", "pmc_pattern_phases_P83.txt", "pmc_sq_pattern_kernel.txt",
              "footprint_sweep.txt", "bench_cfg4_pf_125000.json", "bench_cfg4_pf_10000.json", "bench_cfg4_shared_125000.json", "bench_cfg5_12500.json",
              "bench_cfg5_chunks1.json", "bench_cfg5_chunks2.json", "bench_cfg5_chunks4.json", "bench_cfg5_chunks8.json",
              "bench_cfg1.json", "bench_cfg2.json", "bench_cfg3.json", "bench_cfg4.json", "bench_cfg5.json", "bench_cfg2_pattern_per_frame.json",
@@ -57,7 +119,10 @@ def main():
     for tag in ("cfg2", "cfg2pf", "cfg5", "cfg4pf"):
         st = newest(os.path.join(src, f"prof_{tag}", "**", "*_kernel_stats.csv"))
         if st:
-            shutil.copy(st, os.path.join(dst, f"{R}_{tag}_kernel_stats.csv"))
+            shutil.copy(st, os.path.join(dst, f"{R}_{tag}_kernel_stats_all_launches.csv"))
+        tr = newest(os.path.join(src, f"prof_{tag}", "**", "*_kernel_trace.csv"))
+        if tr:
+            timed_region_stats(tr, os.path.join(src, f"prof_{tag}.json"), os.path.join(dst, f"{R}_{tag}_kernel_stats.csv"))
         j = os.path.join(src, f"prof_{tag}.json")
         if os.path.exists(j):
             shutil.copy(j, os.path.join(dst, f"{R}_{tag}_bench_under_rocprof.json"))
@@ -92,6 +157,7 @@ def main():
         }
         json.dump(rec, open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
         print("pmc_traffic.json:", json.dumps(rec["frame_kernel"]), "ratio %.4f" % ((fw + fr) / alg), "commit", commit)
+    mfma_busy(src, dst, R)
 
 
 if __name__ == "__main__":

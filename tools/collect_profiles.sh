@@ -1,9 +1,10 @@
 #!/bin/bash
-# Collects the round's measured artefacts on the GPU box into gpurun_out/r03/ (copied into profiles/ afterwards by tools/assemble_profiles.py).
-#   bash tools/collect_profiles.sh [part]     part = bench | prof | tools | all
+# Collects the round's measured artefacts on the GPU box into gpurun_out/$ROUND/ (copied into profiles/ afterwards by tools/assemble_profiles.py).
+#   [ROUND=r04] bash tools/collect_profiles.sh [part]     part = bench | prof | mfma | tools | all
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-O=$R/gpurun_out/r03
+ROUND=${ROUND:-r04}
+O=$R/gpurun_out/$ROUND
 mkdir -p $O
 part=${1:-all}
 cd $R
@@ -29,6 +30,14 @@ if [ "$part" = prof ] || [ "$part" = all ]; then
   timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_cfg4pf -- python3 $R/bench.py --workload cfg4_dataset_mixed --pattern-group 1 --no-cpu-baseline --steps 10 > $O/prof_cfg4pf.json 2> $O/prof_cfg4pf.err
   cd $R
   echo prof done
+fi
+if [ "$part" = mfma ] || [ "$part" = all ]; then
+  # MFMA-pipe busy of the full-covariance filter GEMM at the bench's 2 304 frames (counters in a run of their own, kernel trace only)
+  cd /tmp && export TMPDIR=/tmp
+  timeout -k 10 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_mfma -- python3 $R/bench.py --workload cfg5_4x4_2048_fullcov --no-cpu-baseline --steps 5 --warmup 2 > $O/pmc_mfma.json 2> $O/pmc_mfma.err
+  cd $R
+  python3 tools/assemble_profiles.py --round $ROUND --only-mfma > $O/pmc_mfma_cgemm.txt 2>&1
+  echo mfma done
 fi
 if [ "$part" = tools ] || [ "$part" = all ]; then
   timeout -k 10 200 python tools/stamps_patterns.py > $O/stamps_pattern_kernel.txt 2>&1

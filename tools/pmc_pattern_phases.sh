@@ -2,7 +2,7 @@
 # instructions per phase of pattern_build_kernel<compact>: SQ instruction counters of the kernel truncated after phase k
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-O=$R/gpurun_out/r03/pmc_phases
+O=$R/gpurun_out/${ROUND:-r04}/pmc_phases
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_BRANCH SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE SQ_INSTS_SMEM --kernel-trace --output-format csv -d $O/a -- python3 $R/tools/pattern_phases.py ${1:-838} > $O/a.txt 2> $O/a.err
@@ -10,7 +10,7 @@ cd $R
 python3 - <<'PY'
 import csv, glob, collections
 names = ["selection", "slot table", "row tables + strips", "pockets", "flips", "compact table + walk"]
-for f in glob.glob("gpurun_out/r03/pmc_phases/a/**/*counter_collection.csv", recursive=True):
+for f in glob.glob("gpurun_out/" + __import__("os").environ.get("ROUND", "r04") + "/pmc_phases/a/**/*counter_collection.csv", recursive=True):
     rows = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         if "pattern_build" in r["Kernel_Name"]:

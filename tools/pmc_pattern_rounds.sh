@@ -1,7 +1,7 @@
 #!/bin/bash
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-O=$R/gpurun_out/r03/pmc_rounds
+O=$R/gpurun_out/${ROUND:-r04}/pmc_rounds
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/a -- python3 $R/tools/pattern_rounds.py ${1:-838} > $O/a.txt 2> $O/a.err
@@ -9,7 +9,7 @@ cd $R
 python3 - <<'PY'
 import csv, glob, collections
 caps = (1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 16, 40)
-for f in glob.glob("gpurun_out/r03/pmc_rounds/a/**/*counter_collection.csv", recursive=True):
+for f in glob.glob("gpurun_out/" + __import__("os").environ.get("ROUND", "r04") + "/pmc_rounds/a/**/*counter_collection.csv", recursive=True):
     rows = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         if "pattern_build" in r["Kernel_Name"]:

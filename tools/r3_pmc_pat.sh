@@ -1,7 +1,7 @@
 #!/bin/bash
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-O=$R/gpurun_out/r03/pmc_pat
+O=$R/gpurun_out/${ROUND:-r04}/pmc_pat
 mkdir -p $O
 rocprofv3 -L 2>/dev/null | grep -i -E "Counter_Name.*(ICACHE|IFETCH|SQC_|INST_LEVEL|SQ_INSTS_BRANCH|SQ_WAIT_INST|SQ_INST_CYCLES)" | head -60 > $O/../icache_counters.txt; cat $O/../icache_counters.txt
 cd /tmp && export TMPDIR=/tmp
@@ -12,7 +12,7 @@ cd $R
 python3 - <<'PY'
 import csv, glob, collections
 for tag in "abc":
-    for f in glob.glob(f"gpurun_out/r03/pmc_pat/{tag}/**/*counter_collection.csv", recursive=True):
+    for f in glob.glob("gpurun_out/" + __import__("os").environ.get("ROUND", "r04") + f"/pmc_pat/{tag}/**/*counter_collection.csv", recursive=True):
         acc = collections.defaultdict(list)
         for r in csv.DictReader(open(f)):
             if "pattern_build" in r["Kernel_Name"]:
