@@ -93,7 +93,8 @@ struct SlabArgs {
     const float2* csum_g;
     const chest_injected* inj;
     const chest_frame_outputs* out;
-    float2* hp;        // LDS [Pmax*R] LS estimates at the pilots
+    float2* hp;        // LDS [Pmax*R] LS estimates at the pilots; nullptr: no estimates in this launch -- the pilot values go straight
+                       // to out.h_ls_pilots (if asked for) and the slab has the LDS to itself
     float* red;
     float* alpha;
     float2* slab;      // LDS, 16-B aligned
@@ -103,9 +104,12 @@ struct SlabArgs {
 
 // LDS slab segment capacities in float2 elements (even, +2 so that a parity shift of one element fits)
 __host__ __device__ inline int slab_seg(int rows, int nsc) { return ((rows * nsc + 1) & ~1) + 2; }
-__host__ __device__ inline int slab_elems(int T, int RG, int nsc, int SS) {
-    const int w = slab_seg(SS * T, nsc) + slab_seg(SS * RG * T, nsc) + slab_seg(SS * RG, nsc);
-    const int e = 2 * slab_seg(SS * RG * T, nsc);
+// rows of the tx segment: every tx antenna sends the same grid (quirk Q5), and rows two apart start at the same 16-B phase
+// (2 nsc elements = 16 nsc bytes), so two rows serve any number of antennas -- the store-out writes them T / 2 times
+__host__ __device__ inline int tx_rows(int T, int SS) { return (SS == 1 && T > 2) ? 2 : SS * T; }
+__host__ __device__ inline int slab_elems(int T, int RG, int nsc, int SS, bool with_estimates = true) {
+    const int w = slab_seg(tx_rows(T, SS), nsc) + slab_seg(SS * RG * T, nsc) + slab_seg(SS * RG, nsc);
+    const int e = with_estimates ? 2 * slab_seg(SS * RG * T, nsc) : 0;
     return w > e ? w : e;
 }
 
@@ -148,6 +152,14 @@ __device__ __forceinline__ void slab_body(const SlabArgs& A) {
     const float noise_std = A.rec[ST_NOISE_STD];
     float2* __restrict__ hp = A.hp;
     float2* __restrict__ slab = A.slab;
+    // hp == nullptr: pilot estimates leave as 8-B stores into this frame's [R][stride] block (a symbol's pilots have consecutive
+    // ordinals, so the lanes of a wave that hold pilots write neighbouring addresses); no destination: nothing is kept
+    float2* __restrict__ hl_direct = (hp == nullptr && out.h_ls_pilots != nullptr) ? (float2*)out.h_ls_pilots + (size_t)b * R * out.h_ls_stride : nullptr;
+    const bool keep_pilots = hp != nullptr || hl_direct != nullptr;
+    auto put_pilot = [&](unsigned ordinal, int r, float2 v) {
+        if (hp != nullptr) hp[ordinal * R + r] = v;
+        else hl_direct[(size_t)r * out.h_ls_stride + ordinal] = v;
+    };
     float2* __restrict__ txb = out.tx ? (float2*)out.tx + (size_t)b * S * T * nsc : nullptr;
     float2* __restrict__ rxb = out.rx ? (float2*)out.rx + (size_t)b * S * R * nsc : nullptr;
     float2* __restrict__ Hb = out.H ? (float2*)out.H + (size_t)b * S * R * T * nsc : nullptr;
@@ -193,7 +205,8 @@ __device__ __forceinline__ void slab_body(const SlabArgs& A) {
     // SSN consecutive symbols form one unit (STAGED instantiations with RG == R only: a unit's spans stay contiguous across
     // symbols); 1 everywhere else.
     constexpr int SSN = STAGED ? SS : 1;
-    const int seg_tx = 0, seg_h = slab_seg(SSN * T, nsc), seg_rx = seg_h + slab_seg(SSN * RG * T, nsc);
+    const int txr = tx_rows(T, SSN);                             // rows of tx kept in the slab (2 when T > 2: written T / 2 times)
+    const int seg_tx = 0, seg_h = slab_seg(txr, nsc), seg_rx = seg_h + slab_seg(SSN * RG * T, nsc);
     const int ngroups = R / RG;
     bool first_unit = true;
     // Store-out crew.  A workgroup of 4n+1 waves puts two of its waves on one SIMD; the younger of them loses the issue
@@ -254,7 +267,7 @@ __device__ __forceinline__ void slab_body(const SlabArgs& A) {
             }
             xs[ss][0] = cis_unit(__builtin_amdgcn_fractf(u0));                   // exp(j 2pi u) (:395,:399)
             xs[ss][1] = cis_unit(__builtin_amdgcn_fractf(u1));
-            pp[ss][0] = act && ss < ns && sc[ss][0] < (unsigned)P; pp[ss][1] = v1 && ss < ns && sc[ss][1] < (unsigned)P;
+            pp[ss][0] = keep_pilots && act && ss < ns && sc[ss][0] < (unsigned)P; pp[ss][1] = keep_pilots && v1 && ss < ns && sc[ss][1] < (unsigned)P;
         }
         }
         for (int rg = 0; rg < ngroups; ++rg) {
@@ -324,7 +337,7 @@ __device__ __forceinline__ void slab_body(const SlabArgs& A) {
                         if (ss >= ns) continue;
                         if (rg == 0 && txb != nullptr) {
 #pragma unroll
-                            for (int t = 0; t < TT; ++t) put(l_tx + (ss * TT + t) * nsc, xs[ss][0], xs[ss][1]);
+                            for (int t = 0; t < (SSN == 1 && TT > 2 ? 2 : TT); ++t) put(l_tx + (ss * TT + t) * nsc, xs[ss][0], xs[ss][1]);
                         }
 #pragma unroll
                         for (int rr = 0; rr < RGT; ++rr) {
@@ -334,8 +347,8 @@ __device__ __forceinline__ void slab_body(const SlabArgs& A) {
                                 for (int t = 0; t < TT; ++t) put(l_h + ((ss * RGT + rr) * TT + t) * nsc, hv[ss][rr * TT + t][0], hv[ss][rr * TT + t][1]);
                             }
                             if (rxb != nullptr) put(l_rx + (ss * RGT + rr) * nsc, qv[ss][rr][0], qv[ss][rr][1]);
-                            if (pp[ss][0]) hp[sc[ss][0] * R + r] = pilot_divide(qv[ss][rr][0], xs[ss][0]);    // (src/baseline_estimators.py:110)
-                            if (pp[ss][1]) hp[sc[ss][1] * R + r] = pilot_divide(qv[ss][rr][1], xs[ss][1]);
+                            if (pp[ss][0]) put_pilot(sc[ss][0], r, pilot_divide(qv[ss][rr][0], xs[ss][0]));    // (src/baseline_estimators.py:110)
+                            if (pp[ss][1]) put_pilot(sc[ss][1], r, pilot_divide(qv[ss][rr][1], xs[ss][1]));
                         }
                     }
                 }
@@ -348,7 +361,7 @@ __device__ __forceinline__ void slab_body(const SlabArgs& A) {
                 if (!first_unit) __syncthreads();                                // previous unit's store-out has read the slab
                 first_unit = false;
                 if (act && rg == 0 && txb != nullptr) {
-                    for (int t = 0; t < T; ++t) put(l_tx + t * nsc, x0, x1);
+                    for (int t = 0; t < txr; ++t) put(l_tx + t * nsc, x0, x1);
                 }
                 for (int rr = 0; cw && rr < RG; ++rr) {
                     const int r = r0 + rr;
@@ -379,8 +392,8 @@ __device__ __forceinline__ void slab_body(const SlabArgs& A) {
                     const float2 q0 = make_float2(fmaf(noise_std, n0v.x, y0.x), fmaf(noise_std, n0v.y, y0.y));
                     const float2 q1 = make_float2(fmaf(noise_std, n1v.x, y1.x), fmaf(noise_std, n1v.y, y1.y));
                     if (act && rxb != nullptr) put(l_rx + rr * nsc, q0, q1);
-                    if (p0) hp[s0 * R + r] = pilot_divide(q0, x0);               // (src/baseline_estimators.py:110)
-                    if (p1) hp[s1 * R + r] = pilot_divide(q1, x1);
+                    if (p0) put_pilot(s0, r, pilot_divide(q0, x0));              // (src/baseline_estimators.py:110)
+                    if (p1) put_pilot(s1, r, pilot_divide(q1, x1));
                 }
             }
             STAMP_ADD(2);                                                        // W slab writes
@@ -388,7 +401,13 @@ __device__ __forceinline__ void slab_body(const SlabArgs& A) {
             STAMP_ADD(3);                                                        // W barrier A
             if (storer) {
                 int ph = swave;                                                  // rotate the stores of consecutive segments over the waves
-                if (rg == 0 && txb != nullptr) { const int n = seg_store(txb + e_tx, l_tx, ns * T * nsc, ph, nstw); ph = (ph + nstw - n % nstw) % nstw; }
+                if (rg == 0 && txb != nullptr) {
+                    if (txr == ns * T) { const int n = seg_store(txb + e_tx, l_tx, ns * T * nsc, ph, nstw); ph = (ph + nstw - n % nstw) % nstw; }
+                    else                                                         // two slab rows -> rows (0, 1), (2, 3), ... of the symbol
+                        for (int t0 = 0; t0 < T; t0 += 2) {
+                            const int n = seg_store(txb + e_tx + t0 * nsc, l_tx, min(2, T - t0) * nsc, ph, nstw); ph = (ph + nstw - n % nstw) % nstw;
+                        }
+                }
                 if (Hb != nullptr) { const int n = seg_store(Hb + e_h, l_h, ns * RG * T * nsc, ph, nstw); ph = (ph + nstw - n % nstw) % nstw; }
                 if (rxb != nullptr) seg_store(rxb + e_rx, l_rx, ns * RG * nsc, ph, nstw);
             }
@@ -428,9 +447,14 @@ __device__ __forceinline__ void slab_body(const SlabArgs& A) {
     }
     if (out.h_ls_pilots != nullptr) {                // LS estimates at the pilots, [R][stride] per frame, zero padded
         float2* __restrict__ hl = (float2*)out.h_ls_pilots + (size_t)b * R * out.h_ls_stride;
-        for (int i = tid; i < R * out.h_ls_stride; i += blockDim.x) {
-            const int r = i / out.h_ls_stride, p = i - r * out.h_ls_stride;
-            hl[i] = p < P ? hp[p * R + r] : make_float2(0.f, 0.f);
+        if (hp != nullptr) {
+            for (int i = tid; i < R * out.h_ls_stride; i += blockDim.x) {
+                const int r = i / out.h_ls_stride, p = i - r * out.h_ls_stride;
+                hl[i] = p < P ? hp[p * R + r] : make_float2(0.f, 0.f);
+            }
+        } else {                                                                 // the values are there already: only the zero padding
+            const int npad = out.h_ls_stride - P;
+            for (int i = tid; i < R * npad; i += blockDim.x) hl[(size_t)(i / npad) * out.h_ls_stride + P + i % npad] = make_float2(0.f, 0.f);
         }
     }
     if (!want_est) return;
@@ -706,8 +730,11 @@ frame_slab_kernel(const FrameParams* __restrict__ fpp, const chest_frame_desc* _
     A.c_g = (const float2*)(rec + ST_SCAL);
     A.csum_g = A.c_g + (size_t)S * R * T * KTS;
     A.inj = &inj; A.out = &out;
-    A.hp = (float2*)lds_raw;                                     // [Pmax*R rounded up to even]
-    A.red = (float*)(A.hp + (((size_t)Pmax * R + 1) & ~(size_t)1));   // [32]
+    // (a launch that produces no estimate -- the full-covariance route reads h_ls_pilots instead -- keeps no pilot table in LDS:
+    //  53.7 KB at 4x4 / P = 1 678, which is what lets two such workgroups share a CU)
+    const size_t hp_elems = want_est ? (((size_t)Pmax * R + 1) & ~(size_t)1) : 0;
+    A.hp = want_est ? (float2*)lds_raw : nullptr;                // [Pmax*R rounded up to even]
+    A.red = (float*)((float2*)lds_raw + hp_elems);               // [32]
     A.alpha = A.red + 32;                                        // [8]
     A.slab = (float2*)(A.alpha + 8);                             // 16-B aligned: hp span is a multiple of 16 B, 40 floats = 160 B
     const uint64_t frame = frame_offset + (uint64_t)b;
@@ -731,8 +758,9 @@ frame_slab_kernel(const FrameParams* __restrict__ fpp, const chest_frame_desc* _
 #endif
 }
 
-size_t slab_lds_bytes(int nsc, int T, int R, int RG, int Pmax, int SS) {
-    return ((((size_t)Pmax * R + 1) & ~(size_t)1) + (size_t)slab_elems(T, RG, nsc, SS)) * sizeof(float2) + 40 * sizeof(float);
+size_t slab_lds_bytes(int nsc, int T, int R, int RG, int Pmax, int SS, bool with_estimates = true) {
+    const size_t hp = with_estimates ? (((size_t)Pmax * R + 1) & ~(size_t)1) : 0;
+    return (hp + (size_t)slab_elems(T, RG, nsc, SS, with_estimates)) * sizeof(float2) + 40 * sizeof(float);
 }
 
 // Rx antennas per unit: the largest divisor of R whose slab still lets two workgroups share a CU's 160 KiB of LDS (long
@@ -785,7 +813,9 @@ int launch_k2_slab(chest_ctx* ctx, hipStream_t st, int32_t B, const chest_frame_
 #endif
     constexpr int SS_SISO = CHEST_SS_SISO;
     const bool siso = !injected && !(fp.half & 1) && nwave <= 5 && T == 1 && R == 1 && RG == 1;
-    const size_t lds = slab_lds_bytes(fp.nsc, fp.T, fp.R, RG, Pmax, siso ? SS_SISO : 1);
+    // a launch without estimates (H_ls / H_mmse / metrics) keeps neither the pilot table nor the estimate segments in LDS
+    const bool want_est = out.H_ls != nullptr || out.H_mmse != nullptr || out.metrics != nullptr;
+    const size_t lds = slab_lds_bytes(fp.nsc, fp.T, fp.R, RG, Pmax, siso ? SS_SISO : 1, want_est);
     if (lds > 160 * 1024) { set_error("frame kernel needs %zu B of LDS (> 160 KiB): too many antennas, subcarriers or pilots", lds); return CHEST_EINVAL; }
     const dim3 grid((unsigned)B), block((unsigned)(nwave + nsx) * 64);
 #define CHEST_SLAB_ARGS st, grid, block, lds, descs, Pmax, seed, frame_offset, inj, out, workspace, RGarg
@@ -814,6 +844,10 @@ int launch_k2_slab(chest_ctx* ctx, hipStream_t st, int32_t B, const chest_frame_
         return launch_one<448, 4, 0, 0, 0, 1, true>(ctx, LDS_FRAME_GEN, CHEST_SLAB_ARGS);
     }
     if (nwave <= 10) {                     // the 2048-FFT grids (nsc <= 1280)
+        // (4x4 without estimates -- the full-covariance route -- needs 67 KB: two workgroups would fit a CU with a 96-VGPR
+        //  instantiation (five waves per SIMD).  Built and measured in round 4: 54 spilled registers, 2.00 against 1.90 ms per
+        //  2 304 frames, 4.23 against 4.01 per 4 608 -- the synthesis is bound by the instructions it issues, not by residency;
+        //  profiles/r04_cfg5_frame_kernel_isa.txt.  Not kept.)
         if (!injected && !(fp.half & 1) && T == 4 && R == 4 && RG == 1) return launch_one<768, 3, 4, 4, 1, 1, false>(ctx, LDS_FRAME_640_44, CHEST_SLAB_ARGS);
         return launch_one<768, 3, 0, 0, 0, 1, true>(ctx, LDS_FRAME_640, CHEST_SLAB_ARGS);
     }
