@@ -40,6 +40,7 @@ PKG = "channel-estimation-in-5g-network_amd"
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+MFMA_F16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: ~2.5 PF dense, v_mfma_f32_32x32x16_f16 / _bf16
 
 WORKLOADS = {
     # kind "frames": one chest_frames_run per step, identical parameters for every frame
@@ -579,25 +580,27 @@ def measure_leg(job, args, workload, group, steps, warmup, frames=None, patterns
         if "plan_kernels" in kern:
             cfgd["plan_build_kernel_ms"] = kern["plan_kernels"]
         if kind == "fullcov":
-            gemm_ms = kern.get("cgemm_w_kernel_3m", 0.0)             # per launch; a step launches it once per pipeline chunk
-            flop = 8.0 * P * P * R * F / nch                         # one right-hand side per (frame, rx): quirk Q9
-            ach = flop / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+            gemm_ms = kern.get("cgemm_w_kernel", 0.0)                # per launch; a step launches it once per pipeline chunk
             step_ms = dt / steps * 1e3
             hbm = bytes_frame * F / (step_ms * 1e-3) / 1e9
-            # `achieved` prices the 8 P^2 flop per right-hand side the result represents (4 real multiply-adds per complex one);
-            # the 3-multiplication form the kernel runs issues 3/4 of them on the MFMA pipe: `issued_*` is that figure
-            # `achieved` / `frac`: the MFMA work the kernel ISSUES (the 3-multiplication complex product runs 6 P^2 of the 8 P^2
-            # real flop per right-hand side the result represents) -- a roofline fraction, <= 1 by construction; `algorithmic_*`
-            # prices the represented 8 P^2 R flop per frame (R, not R T: one right-hand side per (frame, rx), quirk Q9) and may
-            # exceed the peak for that reason
-            roof = {"bound": "mfma", "achieved": 0.75 * ach, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": 0.75 * ach / MFMA_F32_PEAK_TFLOPS, "issued_TFLOPs": 0.75 * ach, "issued_frac": 0.75 * ach / MFMA_F32_PEAK_TFLOPS,
-                    "algorithmic_TFLOPs": ach, "algorithmic_frac": ach / MFMA_F32_PEAK_TFLOPS,
-                    "flop_note": "issued = 6 P^2 R per frame (3M complex product); algorithmic = 8 P^2 R per frame; R not R*T: tx-replicated right-hand sides (Q9)",
-                    "traffic": None, "kernel": "cgemm_w_kernel_3m", "kernel_ms": gemm_ms,
-                    "flop_per_frame": 8.0 * P * P * R, "kernels_ms": kern, "call_ms": call_ms,
+            # The step's dominant kernel is the frame kernel (HBM-bound): `achieved` / `frac` = the bytes IT writes (tx, rx, H, mask,
+            # pilot symbols, h_ls_pilots) over its own duration; `step_frac` = SURVEY 8d's bytes of the whole path over the whole step.
+            fk_bytes = 8 * S * nsc * (T + R + R * T) + S * nsc + 8 * P + 8 * R * ((P + 15) // 16 * 16)
+            fk_ach = fk_bytes * F / nch / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
+            # The filter W h runs on the fp16 MFMA pipe, each f32 operand split in two fp16 terms (f32-accurate: DESIGN 5 K4): per
+            # right-hand side the 3-multiplication complex product is 3 real products x 3 fp16 MFMA terms x 2 P^2 flop = 18 P^2 ISSUED
+            # flop for the 8 P^2 the result represents (R right-hand sides per frame, not R T: quirk Q9).
+            issued = 18.0 * P * P * R * F / nch / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+            algo = 8.0 * P * P * R * F / nch / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+            roof = {"bound": "hbm", "achieved": fk_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": fk_ach / HBM_PEAK_GBS,
+                    "step_frac": hbm / HBM_PEAK_GBS, "traffic": None, "kernel": "frame_slab_kernel", "kernel_ms": kern_ms,
+                    "frame_kernel_bytes_per_frame": fk_bytes, "kernels_ms": kern, "call_ms": call_ms,
                     "hbm_whole_step": {"bytes_per_frame": bytes_frame, "achieved_GBps": hbm, "frac": hbm / HBM_PEAK_GBS},
-                    "step_frac": hbm / HBM_PEAK_GBS}
+                    "mfma": {"kernel": "cgemm_w_kernel_h2", "kernel_ms": gemm_ms, "dtype": "f16 x f16 -> f32 (two-term fp16 split of the f32 operands)",
+                             "issued_TFLOPs": issued, "peak": MFMA_F16_PEAK_TFLOPS, "issued_frac": issued / MFMA_F16_PEAK_TFLOPS,
+                             "algorithmic_TFLOPs": algo, "algorithmic_vs_f32_mfma_peak": algo / MFMA_F32_PEAK_TFLOPS,
+                             "flop_note": "issued = 18 P^2 R per frame on the fp16 pipe; algorithmic = 8 P^2 R per frame (the f32-MFMA kernel of "
+                                          "rounds 1-3, chest_tune gemm_f32, issued 6 P^2 R at 0.76 of the 157.3 TFLOP/s f32 peak)"}}
         else:
             achieved = bytes_frame * F / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
             traffic, tsrc = _pmc_traffic(workload, F, group)
@@ -651,8 +654,8 @@ def _brief(res):
          "pattern_group": res["config"]["pattern_group"]}
     if "plan_build_kernel_ms" in res["config"]:
         b["pattern_kernel_ms"] = res["config"]["plan_build_kernel_ms"]
-    if r["bound"] == "mfma":
-        b["issued_frac"] = r["issued_frac"]; b["algorithmic_frac"] = r["algorithmic_frac"]; b["kernels_ms"] = r["kernels_ms"]
+    if "mfma" in r:
+        b["mfma"] = {k: r["mfma"][k] for k in ("kernel", "kernel_ms", "issued_TFLOPs", "issued_frac", "algorithmic_TFLOPs")}; b["kernels_ms"] = r["kernels_ms"]
     if "snr_sweep" in res:
         b["snr_sweep"] = res["snr_sweep"]
     b["triangulation"] = res["config"].get("triangulation")

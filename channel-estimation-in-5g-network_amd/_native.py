@@ -16,7 +16,7 @@ NUM_METRICS = 8
 M_SUM_H2, M_SUM_ERR_LS, M_SUM_ERR_MMSE, M_SIGNAL_POWER, M_NOISE_STD, M_ALPHA0, M_COUNT = range(7)
 ABI_VERSION = 2
 FRAME_OK, FRAME_BAD_DESC, FRAME_NO_PLAN = 0, 1, 2
-KERNEL_IDS = {"taps_kernel": 0, "frame_kernel": 1, "pack_kernels": 2, "cgemm_w_kernel_3m": 3, "interp_from_pilots_kernel": 4,
+KERNEL_IDS = {"taps_kernel": 0, "frame_kernel": 1, "pack_kernels": 2, "cgemm_w_kernel": 3, "interp_from_pilots_kernel": 4,
               "plan_kernels": 5}
 CHANNEL_CODES = {"EPA": 0, "EVA": 1, "ETU": 2}
 

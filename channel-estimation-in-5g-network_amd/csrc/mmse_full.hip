@@ -156,6 +156,213 @@ cgemm_w_kernel_3m(int P, int Kpad, int M, int ldo, const float2* __restrict__ Wp
         }
 }
 
+// ---- the same product on the fp16 MFMA pipe, float32-accurate (round 4) ---------------------------------------------------------------
+// v_mfma_f32_32x32x16_f16 retires 16 x the multiply-adds of v_mfma_f32_32x32x2_f32 per cycle.  Each REAL operand x of the
+// 3-multiplication form is split into two fp16 numbers, x s = hi + lo with hi = fp16(x s), lo = fp16(x s - hi) and s a power of two
+// that puts the largest magnitude of the operand at 2^14 (fp16's largest finite value is 65504), and a real product is
+//     x y  =  (hi_x hi_y + hi_x lo_y + lo_x hi_y) / (s_x s_y)  +  O(2^-22 |x| |y|)
+// -- three fp16 MFMAs into ONE float32 accumulator (products of fp16 numbers are exact in float32; the dropped lo_x lo_y term and the
+// representation error are 2^-22 relative, below float32's own rounding of the sum).  Nine fp16 MFMAs replace three f32 ones: 9 / 16 / 3 =
+// 0.19 of the matrix-pipe time.  Measured error of W h against float64 at P = 1 678: 7.3e-7 of max|W h| (f32 3M form: 8.7e-7;
+// tools/fp16_split_model.py).  Elements 2^11 and more below the operand's largest lose their lo part to fp16's subnormal range; their
+// error is then 2^-11 of 2^-11 of the largest, i.e. the same 2^-22 of the scale the result is judged on.
+//
+// Operands are packed by pack_h2_kernel in the order the GEMM stages them: [row tile of 128][k stage of 16][plane][128 rows][16 k] fp16,
+// planes = (re hi, re lo, im hi, im lo, (re + im) hi, (re + im) lo), so a stage of one operand is ONE contiguous 24 KB block.
+typedef _Float16 h8_t __attribute__((ext_vector_type(8)));
+constexpr int H2_ROWB = 48;                                  // LDS bytes per (row, plane): 32 B of k + 16 B pad -> conflict-free ds_read_b128
+constexpr int H2_PLANE = 128 * H2_ROWB;                      // one plane of one operand tile
+constexpr size_t H2_LDS_BYTES = (size_t)2 * 2 * 6 * H2_PLANE;   // 2 buffers x (A, B) x 6 planes = 147 456 B: one workgroup per CU
+
+// largest power of two s with 2 amax s <= 2^14 (the sum plane holds re + im); 1 for an all-zero operand
+__device__ __forceinline__ float h2_scale(float amax) {
+    if (!(amax > 0.f)) return 1.0f;
+    int e;
+    (void)frexpf(2.0f * amax, &e);                           // 2 amax = m 2^e, 0.5 <= m < 1
+    return ldexpf(1.0f, 14 - e);
+}
+
+// largest |x[r][c]|, c < cols, of a [rows][ld] float array (pad columns beyond cols are not looked at; ld and cols multiples of 4,
+// rows 16-B aligned): one row per pass of a workgroup, float4 loads
+__global__ void __launch_bounds__(256)
+absmax_kernel(int rows, int cols, int ld, const float* __restrict__ x, unsigned* __restrict__ out) {
+    float m = 0.f;
+    for (int r = blockIdx.x; r < rows; r += gridDim.x) {
+        const float* xr = x + (size_t)r * ld;
+        const int c4 = (((uintptr_t)xr & 15) == 0) ? cols >> 2 : 0;          // float4 loads where the row starts on a 16-B boundary
+        for (int c = threadIdx.x; c < c4; c += blockDim.x) {
+            const float4 v = ((const float4*)xr)[c];
+            m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));      // (fmaxf drops a NaN; the GEMM propagates it)
+        }
+        for (int c = (c4 << 2) + threadIdx.x; c < cols; c += blockDim.x) m = fmaxf(m, fabsf(xr[c]));
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(out, __float_as_uint(m));      // non-negative floats order like their bit patterns
+}
+
+// X [rows][ld] complex64 (valid: nr rows x P columns) -> packed fp16 planes (layout above).  Workgroup (row tile, chunk of k stages):
+// thread (row tid >> 1, half tid & 1) reads its 8 complex values of a stage (two threads = 128 contiguous bytes of a row) and writes
+// one 16-B piece of each plane; the 256 pieces of a plane are 4 KB contiguous.
+constexpr int H2_PACK_KS = 15;                               // k stages per workgroup
+__global__ void __launch_bounds__(256)
+pack_h2_kernel(int nr, int P, int ld, int Kpad, const float2* __restrict__ X, const unsigned* __restrict__ amax, _Float16* __restrict__ Q) {
+    const int tile = blockIdx.x, r = threadIdx.x >> 1, half = threadIdx.x & 1, row = tile * 128 + r;
+    const int nks = Kpad >> 4;
+    const float s = h2_scale(__uint_as_float(*amax));
+    const int ks1 = min(nks, ((int)blockIdx.y + 1) * H2_PACK_KS);
+    for (int ks = (int)blockIdx.y * H2_PACK_KS; ks < ks1; ++ks) {
+        h8_t pl[6];
+        const int k0 = ks * 16 + half * 8;
+        float2 v[8];
+        if (row < nr && k0 + 8 <= P && (((uintptr_t)(X + (size_t)row * ld + k0)) & 15) == 0) {
+            const float4* src = (const float4*)(X + (size_t)row * ld + k0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const float4 q = src[j]; v[2 * j] = make_float2(q.x, q.y); v[2 * j + 1] = make_float2(q.z, q.w); }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = (row < nr && k0 + j < P) ? X[(size_t)row * ld + k0 + j] : make_float2(0.f, 0.f);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float c[3] = {v[j].x * s, v[j].y * s, (v[j].x + v[j].y) * s};
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const _Float16 hi = (_Float16)c[q];
+                pl[2 * q][j] = hi;
+                pl[2 * q + 1][j] = (_Float16)(c[q] - (float)hi);
+            }
+        }
+        _Float16* base = Q + ((((size_t)tile * nks + ks) * 6) * 128 + r) * 16 + 8 * half;
+#pragma unroll
+        for (int q = 0; q < 6; ++q) *(h8_t*)(base + (size_t)q * 128 * 16) = pl[q];
+    }
+}
+
+// Hout[m][i] = sum_k W[i][k] h[m][k]: 128 x 128 block tile, 4 waves x (2 x 2) 32x32 tiles (rows of the MFMA tile = m, columns = i, as
+// in cgemm_w_kernel_3m: the epilogue is the same), ONE workgroup per CU (147 KB of LDS, up to 512 registers per lane).
+__global__ void __launch_bounds__(256, 1)
+cgemm_w_kernel_h2(int P, int Kpad, int M, int ldo, const _Float16* __restrict__ Wq, const _Float16* __restrict__ Hq,
+                  const unsigned* __restrict__ amax, float2* __restrict__ Hout) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    // Tile order: workgroups are dealt round-robin to the 8 XCDs; each XCD walks a contiguous run of tiles in i-major order, so the
+    // workgroups resident on an XCD at one time share one or two W panels (2.6 MB of planes each: L2 hits) and stream different h tiles.
+    const int nty = (M + T2_M - 1) / T2_M, ntx = (P + T2_N - 1) / T2_N, ntiles = ntx * nty;
+    const int per = (ntiles + 7) >> 3;
+    const int tile = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+    if ((int)(blockIdx.x >> 3) >= per || tile >= ntiles) return;             // (uniform)
+    const int bx = tile / nty, by = tile - bx * nty;
+    const int i0 = bx * T2_N, m0 = by * T2_M;
+    const int wm = (wave & 1) * 64, wi = (wave >> 1) * 64;
+    const int nks = Kpad >> 4;
+    f32x16 acc[3][2][2];                          // sum re*re, sum im*im, sum (re+im)*(re+im), each already the three-term fp16 product
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+        for (int x = 0; x < 2; ++x)
+#pragma unroll
+            for (int y = 0; y < 2; ++y)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[p][x][y][e] = 0.f;
+    // a stage of an operand is 1 536 16-B chunks, chunk q = plane * 256 + row * 2 + half: thread tid takes (row tid >> 1, half tid & 1)
+    // of every plane
+    typedef unsigned u4_t __attribute__((ext_vector_type(4)));
+    const u4_t* gh = (const u4_t*)(Hq + (size_t)by * nks * 6 * 128 * 16) + tid;
+    const u4_t* gw = (const u4_t*)(Wq + (size_t)bx * nks * 6 * 128 * 16) + tid;
+    const unsigned st_off = (unsigned)((tid >> 1) * H2_ROWB + (tid & 1) * 16);
+    // fragment of a 32-row tile: lane l holds row (l & 31), k = 8 (l >> 5) ... + 7: one 16-B read
+    const unsigned fr_off = (unsigned)((lane & 31) * H2_ROWB + (lane >> 5) * 16);
+    u4_t pa[12];                                 // the next stage, in flight while this one is multiplied
+#define H2_FETCH(R, ks)                                                                                                   \
+    do {                                                                                                                  \
+        const int ks_ = (ks) < nks ? (ks) : nks - 1;             /* (past the end: re-read the last stage, no branch) */    \
+        const u4_t* a_ = gh + (size_t)ks_ * 1536; const u4_t* b_ = gw + (size_t)ks_ * 1536;                                 \
+        _Pragma("unroll") for (int q_ = 0; q_ < 6; ++q_) { R[q_] = a_[q_ * 256]; R[6 + q_] = b_[q_ * 256]; }                \
+    } while (0)
+#define H2_STAGE(R, buf)                                                                                                  \
+    do {                                                                                                                  \
+        unsigned char* Hs_ = lds_raw + (size_t)(buf) * 2 * 6 * H2_PLANE + st_off; unsigned char* Ws_ = Hs_ + 6 * H2_PLANE;  \
+        _Pragma("unroll") for (int q_ = 0; q_ < 6; ++q_) { *(u4_t*)(Hs_ + q_ * H2_PLANE) = R[q_]; *(u4_t*)(Ws_ + q_ * H2_PLANE) = R[6 + q_]; } \
+    } while (0)
+    // One wave per SIMD: nothing but this wave's own instruction order hides latencies.  The fragments of a real product are read from
+    // LDS one product AHEAD of the MFMAs that use them (two fragment sets), the next stage's global loads are issued at the top of a
+    // stage and its LDS writes go out between the MFMAs of the stage's last product; sched_barriers pin that order (left alone the
+    // compiler sinks every read to the instruction in front of its first use).
+    h8_t fa[2][2][2], fb[2][2][2];                // [set][hi | lo][tile]: A (h) and B (W) fragments
+#define H2_FRAGS(set, buf, p)                                                                                             \
+    do {                                                                                                                  \
+        const unsigned char* Hs_ = lds_raw + (size_t)(buf) * 2 * 6 * H2_PLANE + fr_off; const unsigned char* Ws_ = Hs_ + 6 * H2_PLANE; \
+        _Pragma("unroll") for (int z_ = 0; z_ < 2; ++z_) {                                                                \
+            fa[set][0][z_] = *(const h8_t*)(Hs_ + (2 * (p)) * H2_PLANE + (wm + 32 * z_) * H2_ROWB);                        \
+            fa[set][1][z_] = *(const h8_t*)(Hs_ + (2 * (p) + 1) * H2_PLANE + (wm + 32 * z_) * H2_ROWB);                    \
+            fb[set][0][z_] = *(const h8_t*)(Ws_ + (2 * (p)) * H2_PLANE + (wi + 32 * z_) * H2_ROWB);                        \
+            fb[set][1][z_] = *(const h8_t*)(Ws_ + (2 * (p) + 1) * H2_PLANE + (wi + 32 * z_) * H2_ROWB);                    \
+        }                                                                                                                 \
+    } while (0)
+#define H2_MFMAS(set, p)                                                                                                  \
+    do {                                                                                                                  \
+        _Pragma("unroll") for (int x = 0; x < 2; ++x)                                                                     \
+            _Pragma("unroll") for (int y = 0; y < 2; ++y) {                                                               \
+                acc[p][x][y] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[set][1][x], fb[set][0][y], acc[p][x][y], 0, 0, 0);   /* small terms first */ \
+                acc[p][x][y] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[set][0][x], fb[set][1][y], acc[p][x][y], 0, 0, 0);   \
+                acc[p][x][y] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[set][0][x], fb[set][0][y], acc[p][x][y], 0, 0, 0);   \
+            }                                                                                                             \
+    } while (0)
+    // (A second register set -- stage t + 2 in flight while t + 1 waits for its LDS writes -- was tried: the compiler spills 104 registers
+    //  and the kernel falls back to the f32 kernel's time.  One stage ahead it is.)
+    H2_FETCH(pa, 0);
+    H2_STAGE(pa, 0);
+    __syncthreads();
+    H2_FRAGS(0, 0, 0);
+    for (int t = 0; t < nks; ++t) {
+        const int buf = t & 1;
+        // region 1: the 12 global loads of stage t + 1 go out ONE PER MFMA of product 0 (issued in a block they cost the wave ~200
+        // cycles in which its matrix pipe drains); product 1's fragments are read meanwhile
+        H2_FRAGS(1, buf, 1);
+        H2_FETCH(pa, t + 1);
+        H2_MFMAS(0, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);       // 8 DS reads
+#pragma unroll
+        for (int i = 0; i < 12; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); }   // MFMA, VMEM read
+        __builtin_amdgcn_sched_barrier(0);
+        // region 2: product 2's fragments, product 1's MFMAs
+        H2_FRAGS(0, buf, 2);
+        H2_MFMAS(1, 1);
+        __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        // region 3: stage t + 1 goes into the other LDS buffer (free since the barrier that ended stage t - 1), ONE write per MFMA of
+        // product 2 (a 1-KB ds_write_b128 occupies the wave ~16-20 cycles; twelve in a row idle the matrix pipe)
+        H2_STAGE(pa, buf ^ 1);
+        H2_MFMAS(0, 2);
+#pragma unroll
+        for (int i = 0; i < 12; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x200, 1, 0); }   // MFMA, DS write
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+        H2_FRAGS(0, buf ^ 1, 0);                  // product 0 of the next stage
+    }
+#undef H2_FRAGS
+#undef H2_MFMAS
+#undef H2_FETCH
+#undef H2_STAGE
+    const float inv = 1.0f / (h2_scale(__uint_as_float(amax[0])) * h2_scale(__uint_as_float(amax[1])));     // exact: powers of two
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y) {
+            const int i = i0 + wi + 32 * y + (lane & 31);
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int m = m0 + wm + 32 * x + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+                if (m < M && i < P) {
+                    const float p1 = acc[0][x][y][reg], p2 = acc[1][x][y][reg];
+                    Hout[(size_t)m * ldo + i] = make_float2((p1 - p2) * inv, (acc[2][x][y][reg] - p1 - p2) * inv);
+                }
+            }
+        }
+}
+
 // W [P][P] -> Wp [Npad][Kpad], zero padded (Npad = P rounded up to the 128-row block tile, Kpad = P rounded up to 16)
 __global__ void __launch_bounds__(256)
 pack_w_kernel(int P, int Kpad, const float2* __restrict__ W, float2* __restrict__ Wp) {
@@ -383,7 +590,50 @@ int chest_mmse_full_prepare(chest_ctx* ctx, void* stream, int32_t P, const doubl
 int64_t chest_mmse_full_apply_scratch_bytes(int32_t P, int32_t num_grids) {
     if (P <= 0 || num_grids <= 0) return 0;
     const int64_t Ppad = pad16(P);
-    return (int64_t)sizeof(float2) * Ppad * ((int64_t)pad128(num_grids) + num_grids + pad128(P));
+    // h_in [Mpad][Ppad] c64 | h_out [M][Ppad] c64 | Hq: six fp16 planes [Mpad][Ppad] | Wq: six fp16 planes [Npad][Ppad] (the f32 path's
+    // packed W [Npad][Ppad] c64 lives there too) | the two operand maxima
+    return Ppad * ((int64_t)sizeof(float2) * (pad128(num_grids) + num_grids) + 12 * ((int64_t)pad128(num_grids) + pad128(P))) + 64;
+}
+
+// W h for M right-hand sides on the matrix pipe.  h_src [M][h_ld] complex64 (rows beyond M and columns beyond P are taken as zero).
+// Default: the fp16-split form (cgemm_w_kernel_h2); chest_tune "gemm_f32" 1: the exact-f32 3-multiplication kernel (A/B).
+static int launch_w_gemm(chest_ctx* ctx, hipStream_t st, int P, int M, const float2* h_src, int h_ld, const float2* W, float* h_scratch,
+                         bool h_src_is_packed_f32) {
+    const int Ppad = pad16(P), Mpad = pad128(M), Npad = pad128(P);
+    float2* h_in = (float2*)h_scratch;
+    float2* h_out = h_in + (size_t)Mpad * Ppad;
+    _Float16* Hq = (_Float16*)(h_out + (size_t)M * Ppad);
+    _Float16* Wq = Hq + (size_t)6 * Mpad * Ppad;
+    unsigned* amax = (unsigned*)(Wq + (size_t)6 * Npad * Ppad);
+    if (ctx->tune_gemm_f32) {
+        float2* w_packed = (float2*)Wq;
+        const float2* h_op = h_src;
+        const int sp_pack = prof_open(ctx, st, CHEST_K_PACK);
+        if (!h_src_is_packed_f32) { hipLaunchKernelGGL(pack_h_kernel, dim3(Mpad), dim3(256), 0, st, M, P, h_ld, Ppad, h_src, h_in); h_op = h_in; }
+        hipLaunchKernelGGL(pack_w_kernel, dim3(Npad), dim3(256), 0, st, P, Ppad, W, w_packed);
+        prof_close(ctx, st, sp_pack);
+        CHEST_LDS_OPT_IN(ctx, LDS_GEMM3M, cgemm_w_kernel_3m, T3_LDS_BYTES);
+        const int sp_gemm = prof_open(ctx, st, CHEST_K_GEMM);
+        hipLaunchKernelGGL(cgemm_w_kernel_3m, dim3(Npad / T2_N, Mpad / T2_M), dim3(256), T3_LDS_BYTES, st, P, Ppad, M, Ppad,
+                           (const float2*)w_packed, h_op, h_out);
+        prof_close(ctx, st, sp_gemm);
+        CHEST_HIP(hipGetLastError());
+        return CHEST_OK;
+    }
+    const int sp_pack = prof_open(ctx, st, CHEST_K_PACK);
+    CHEST_HIP(hipMemsetAsync(amax, 0, 64, st));
+    hipLaunchKernelGGL(absmax_kernel, dim3(256), dim3(256), 0, st, P, 2 * P, 2 * P, (const float*)W, amax);
+    hipLaunchKernelGGL(absmax_kernel, dim3(2048), dim3(256), 0, st, M, 2 * P, 2 * h_ld, (const float*)h_src, amax + 1);
+    hipLaunchKernelGGL(pack_h2_kernel, dim3(Npad / 128, (Ppad / 16 + H2_PACK_KS - 1) / H2_PACK_KS), dim3(256), 0, st, P, P, P, Ppad, W, amax, Wq);
+    hipLaunchKernelGGL(pack_h2_kernel, dim3(Mpad / 128, (Ppad / 16 + H2_PACK_KS - 1) / H2_PACK_KS), dim3(256), 0, st, M, P, h_ld, Ppad, h_src, amax + 1, Hq);
+    prof_close(ctx, st, sp_pack);
+    CHEST_LDS_OPT_IN(ctx, LDS_GEMM, cgemm_w_kernel_h2, H2_LDS_BYTES);
+    const int sp_gemm = prof_open(ctx, st, CHEST_K_GEMM);
+    hipLaunchKernelGGL(cgemm_w_kernel_h2, dim3((((Npad / T2_N) * (Mpad / T2_M) + 7) / 8) * 8), dim3(256), H2_LDS_BYTES, st, P, Ppad, M, Ppad,
+                       (const _Float16*)Wq, (const _Float16*)Hq, (const unsigned*)amax, h_out);
+    prof_close(ctx, st, sp_gemm);
+    CHEST_HIP(hipGetLastError());
+    return CHEST_OK;
 }
 
 int chest_mmse_full_apply(chest_ctx* ctx, void* stream, int32_t B, const float* rx4d, const float* tx_pilots,
@@ -403,17 +653,16 @@ int chest_mmse_full_apply(chest_ctx* ctx, void* stream, int32_t B, const float* 
     const auto& f = ctx->fp;
     const PatternDev& pd = ctx->patterns[slot].dev;
     const int P = pd.P, Ppad = pad16(P), M = B * f.R * f.T;
-    // scratch layout (chest_mmse_full_apply_scratch_bytes): h_in [Mpad][Ppad] | h_out [M][Ppad] | Wp [Npad][Ppad]
-    const int Mpad = pad128(M), Npad = pad128(P);
+    // scratch layout: chest_mmse_full_apply_scratch_bytes
+    const int Mpad = pad128(M);
     float2* h_in = (float2*)h_scratch;
     float2* h_out = h_in + (size_t)Mpad * Ppad;
-    float2* w_packed = h_out + (size_t)M * Ppad;
     hipLaunchKernelGGL(gather_ls_kernel, dim3(Mpad), dim3(256), 0, st, f.S, f.R, f.T, f.nsc, P, Ppad, M, pd.pilot_idx,
                        (const float2*)rx4d, (const float2*)tx_pilots, pilot_stride, h_in);
-    hipLaunchKernelGGL(pack_w_kernel, dim3(Npad), dim3(256), 0, st, P, Ppad, (const float2*)W, w_packed);
-    CHEST_LDS_OPT_IN(ctx, LDS_GEMM3M, cgemm_w_kernel_3m, T3_LDS_BYTES);
-    hipLaunchKernelGGL(cgemm_w_kernel_3m, dim3(Npad / T2_N, Mpad / T2_M), dim3(256), T3_LDS_BYTES, st, P, Ppad, M, Ppad,
-                       (const float2*)w_packed, h_in, h_out);
+    {
+        const int rc = launch_w_gemm(ctx, st, P, M, h_in, Ppad, (const float2*)W, h_scratch, true);
+        if (rc != CHEST_OK) return rc;
+    }
     const size_t lds = (size_t)P * sizeof(float2);
     CHEST_LDS_OPT_IN(ctx, LDS_INTERP, interp_from_pilots_kernel, lds);
     hipLaunchKernelGGL(interp_from_pilots_kernel, dim3(M), dim3(256), lds, st, f.S, f.R, f.T, f.nsc, Ppad, ctx->d_patterns,
@@ -447,25 +696,11 @@ int chest_mmse_full_filter_pilots(chest_ctx* ctx, void* stream, int32_t B, const
     const PatternDev& pd = ctx->patterns[slot].dev;
     const int P = pd.P, Ppad = pad16(P), M = B * f.R;                     // one right-hand side per (frame, rx)
     if (h_ls_stride < P) { set_error("h_ls_stride %d < %d pilots", h_ls_stride, P); return CHEST_EINVAL; }
-    const int Mpad = pad128(M), Npad = pad128(P);
-    float2* h_in = (float2*)h_scratch;
-    float2* h_out = h_in + (size_t)Mpad * Ppad;
-    float2* w_packed = h_out + (size_t)M * Ppad;
-    // chest_frames_run writes h_ls_pilots with the entries P .. h_ls_stride - 1 zeroed: with the row stride of the GEMM operand and
-    // a whole number of 128-row tiles it IS the packed operand -- no copy
+    // chest_frames_run writes h_ls_pilots with the entries P .. h_ls_stride - 1 zeroed: with the row stride of the f32 GEMM operand and
+    // a whole number of 128-row tiles it IS that kernel's packed operand (no copy); the fp16-split form always repacks (into planes)
+    const int Mpad = pad128(M);
     const bool h_in_place = h_ls_stride == Ppad && M == Mpad && ((uintptr_t)h_ls_pilots & 15) == 0;
-    const float2* h_op = h_in_place ? (const float2*)h_ls_pilots : h_in;
-    const int sp_pack = prof_open(ctx, st, CHEST_K_PACK);
-    if (!h_in_place) hipLaunchKernelGGL(pack_h_kernel, dim3(Mpad), dim3(256), 0, st, M, P, h_ls_stride, Ppad, (const float2*)h_ls_pilots, h_in);
-    hipLaunchKernelGGL(pack_w_kernel, dim3(Npad), dim3(256), 0, st, P, Ppad, (const float2*)W, w_packed);
-    prof_close(ctx, st, sp_pack);
-    CHEST_LDS_OPT_IN(ctx, LDS_GEMM3M, cgemm_w_kernel_3m, T3_LDS_BYTES);
-    const int sp_gemm = prof_open(ctx, st, CHEST_K_GEMM);
-    hipLaunchKernelGGL(cgemm_w_kernel_3m, dim3(Npad / T2_N, Mpad / T2_M), dim3(256), T3_LDS_BYTES, st, P, Ppad, M, Ppad,
-                       (const float2*)w_packed, h_op, h_out);
-    prof_close(ctx, st, sp_gemm);
-    CHEST_HIP(hipGetLastError());
-    return CHEST_OK;
+    return launch_w_gemm(ctx, st, P, M, (const float2*)h_ls_pilots, h_ls_stride, (const float2*)W, h_scratch, h_in_place);
 }
 
 int chest_mmse_full_interp_pilots(chest_ctx* ctx, void* stream, int32_t B, int32_t slot, const float* h_scratch, float* H_est) {

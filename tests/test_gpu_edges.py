@@ -340,3 +340,35 @@ def test_full_covariance_apply_ignores_garbage_in_the_pad_columns():
     got = eng.mmse_full_apply_pilots(dirty, slot, W)
     assert torch.isfinite(torch.view_as_real(got)).all() and torch.equal(got, want)
     eng.close()
+
+
+def test_full_covariance_filter_on_the_fp16_pipe_is_float32_accurate():
+    """Round 4: W h runs on v_mfma_f32_32x32x16_f16 with every f32 operand split in two fp16 terms (three products per real
+    product, float32 accumulation; csrc/mmse_full.hip cgemm_w_kernel_h2, tools/fp16_split_model.py).  Against float64 NumPy it must
+    be as accurate as the exact-f32 MFMA kernel it replaces (chest_tune "gemm_f32" 1 keeps that one reachable): config 5's size
+    (P = 1 678) at 10 and 30 dB, and operands of very different magnitudes (the split is scaled per operand)."""
+    import bench
+    geom = E.Geometry(fft_size=2048, cp_length=144, num_symbols=14, useful_subcarriers=1200, num_tx=4, num_rx=4)
+    eng = E.Engine(geom, 0)
+    rs = np.random.RandomState(21)
+    P = geom.grid // 10
+    pil = np.sort(rs.permutation(geom.grid)[:P])
+    slot = eng.pattern_slot(pil, "linear")
+    cov = bench.fullcov_covariance(2048, 144, 1200, 4, "ETU", 555.6, pil)
+    B, R = 40, 4                                                          # 160 right-hand sides: two row tiles, the second ragged
+    for snr, hscale in ((10.0, 1.0), (30.0, 1.0), (10.0, 3.0e-4), (10.0, 700.0)):
+        W = eng.mmse_full_prepare(cov, snr)
+        hls = eng.run_frames(E.make_descs("ETU", 555.6, snr, slot, n=B), seed=9, outputs=("h_ls_pilots",))["h_ls_pilots"] * hscale
+        ref = hls.reshape(B * R, -1)[:, :P].cpu().numpy().astype(np.complex128) @ W.cpu().numpy().astype(np.complex128).T
+        scr = eng.mmse_full_scratch(slot, B * R)
+        errs = {}
+        for f32 in (0, 1):
+            eng.tune("gemm_f32", f32)
+            eng.mmse_full_filter_pilots(hls, slot, W, scr, pads_are_zero=True)
+            Ppad, Mpad = (P + 15) // 16 * 16, (B * R + 127) // 128 * 128
+            got = scr.view(torch.complex64)[Mpad * Ppad: Mpad * Ppad + B * R * Ppad].reshape(B * R, Ppad)[:, :P].cpu().numpy()
+            errs[f32] = float(np.abs(got - ref).max() / np.abs(ref).max())
+        eng.tune("gemm_f32", 0)
+        assert errs[0] < 5e-6 and errs[1] < 5e-6, (snr, hscale, errs)
+        assert errs[0] < 2.0 * errs[1] + 1e-6, (snr, hscale, errs)        # no worse than the f32 kernel
+    eng.close()

@@ -65,7 +65,7 @@ def timed_region_stats(trace_csv, bench_json, out_csv):
 
 
 def mfma_busy(src, dst, R):
-    """MFMA-pipe busy fraction of cgemm_w_kernel_3m from the counter pass of collect_profiles.sh (part mfma): SQ_VALU_MFMA_BUSY_CYCLES
+    """MFMA-pipe busy fraction of the filter GEMM (cgemm_w_kernel_*) from the counter pass of collect_profiles.sh (part mfma): SQ_VALU_MFMA_BUSY_CYCLES
     summed over the chip / (1 024 SIMDs x shader cycles), cycles = GRBM_GUI_ACTIVE / 8 (rocprofv3 sums the 8 XCDs)."""
     cc = newest(os.path.join(src, "pmc_mfma", "**", "*_counter_collection.csv"))
     if not cc:
@@ -73,11 +73,11 @@ def mfma_busy(src, dst, R):
         return
     rows = {}
     for r in csv.DictReader(open(cc)):
-        if "cgemm_w_kernel_3m" in r["Kernel_Name"]:
+        if "cgemm_w_kernel" in r["Kernel_Name"]:
             rows.setdefault(r["Dispatch_Id"], {"grid": r["Grid_Size"], "wg": r["Workgroup_Size"],
                                                "ns": int(r["End_Timestamp"]) - int(r["Start_Timestamp"])})[r["Counter_Name"]] = float(r["Counter_Value"])
     lines = ["# rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace -- python3 bench.py --workload cfg5_4x4_2048_fullcov --no-cpu-baseline --steps 5 --warmup 2",
-             "# cgemm_w_kernel_3m (W h_ls on v_mfma_f32_32x32x2_f32, 3-multiplication complex product), 2 304 frames = 9 216 right-hand sides, P = 1 678",
+             "# cgemm_w_kernel_h2 (W h_ls on v_mfma_f32_32x32x16_f16: 3-multiplication complex product, every f32 operand split in two fp16 terms), 2 304 frames = 9 216 right-hand sides, P = 1 678",
              "# busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8); clock = GRBM_GUI_ACTIVE / 8 / duration",
              "dispatch  grid  duration_ms  clock_GHz  mfma_busy_cycles  mfma_busy_frac"]
     fr = []

@@ -9,7 +9,7 @@ if p and "value" in p:
     print(f"per-frame: {p['value']/1e6:.3f} M  {p['ms_per_step']:.3f} ms  frac {p['frac']:.3f}  pattern {p['pattern_kernel_ms']:.3f} frame {p['frame_kernel_ms']:.3f} taps {p['taps_kernel_ms']:.3f}")
 for k, v in (d.get("also") or {}).items():
     if "value" in v:
-        print(f"  {k}: {v['value']/1e6:.3f} M  {v['ms_per_step']:.3f} ms  frac {v['frac']:.3f} step_frac {v['step_frac']:.3f} kernel_ms {v.get('kernel_ms'):.3f} {v.get('kernels_ms','')}")
+        print(f"  {k}: {v['value']/1e6:.3f} M  {v['ms_per_step']:.3f} ms  frac {v['frac']:.3f} step_frac {v['step_frac']:.3f} kernel_ms {v.get('kernel_ms'):.3f} {v.get('kernels_ms','')} {v.get('mfma','')}")
     else:
         print(f"  {k}: {v}")
 if "cpu_baseline" in d:
