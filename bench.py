@@ -456,6 +456,8 @@ def measure_leg(job, args, workload, group, steps, warmup, frames=None, patterns
         # The step's three legs -- frame kernel (HBM-write-bound), filter W h on the f32 MFMA pipe, interpolation + T-fold stores
         # (HBM-write-bound) -- run as a software pipeline over `nch` chunks of the batch on three streams: the MFMA-bound filter of
         # chunk c beside the HBM-bound kernels of chunks c - 1 / c + 1 (--pipeline-chunks 1: strictly in sequence on one stream).
+        # the filter is packed into the GEMM's operand format once, with the W it belongs to (before the timed region)
+        W = eng.mmse_full_pack_filter(W)
         nch = max(1, min(int(args.pipeline_chunks), F))
         bounds = [(F * c // nch, F * (c + 1) // nch) for c in range(nch)]
         scr = [eng.mmse_full_scratch(slots[0], (b1 - b0) * R) for b0, b1 in bounds]

@@ -94,6 +94,9 @@ SIGNATURES = {
     "chest_mmse_full_apply_scratch_bytes": (_i64, [_i32, _i32]),
     "chest_mmse_full_apply_pilots": (_i32, [_vp, _vp, _i32, _vp, _i32, _i32, _vp, _vp, _vp]),
     "chest_mmse_full_filter_pilots": (_i32, [_vp, _vp, _i32, _vp, _i32, _i32, _vp, _vp]),
+    "chest_mmse_full_packed_filter_bytes": (_i64, [_i32]),
+    "chest_mmse_full_pack_filter": (_i32, [_vp, _vp, _i32, _vp, _vp]),
+    "chest_mmse_full_filter_pilots_packed": (_i32, [_vp, _vp, _i32, _vp, _i32, _i32, _vp, _vp]),
     "chest_mmse_full_interp_pilots": (_i32, [_vp, _vp, _i32, _i32, _vp, _vp]),
     "chest_estimate_dense_scratch_bytes": (_i64, [_vp, _i32, _i32]),
     "chest_estimate_dense": (_i32, [_vp, _vp, _i32, _vp, _vp, _i32, _i32, _vp, _vp, _vp]),

@@ -242,7 +242,7 @@ pack_h2_kernel(int nr, int P, int ld, int Kpad, const float2* __restrict__ X, co
 // Hout[m][i] = sum_k W[i][k] h[m][k]: 128 x 128 block tile, 4 waves x (2 x 2) 32x32 tiles (rows of the MFMA tile = m, columns = i, as
 // in cgemm_w_kernel_3m: the epilogue is the same), ONE workgroup per CU (147 KB of LDS, up to 512 registers per lane).
 __global__ void __launch_bounds__(256, 1)
-cgemm_w_kernel_h2(int P, int Kpad, int M, int ldo, const _Float16* __restrict__ Wq, const _Float16* __restrict__ Hq,
+cgemm_w_kernel_h2(int P, int Kpad, int M, int ldo, const _Float16* __restrict__ Wq, const float2* __restrict__ Hf, int lda,
                   const unsigned* __restrict__ amax, float2* __restrict__ Hout) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
@@ -268,8 +268,12 @@ cgemm_w_kernel_h2(int P, int Kpad, int M, int ldo, const _Float16* __restrict__ 
     // a stage of an operand is 1 536 16-B chunks, chunk q = plane * 256 + row * 2 + half: thread tid takes (row tid >> 1, half tid & 1)
     // of every plane
     typedef unsigned u4_t __attribute__((ext_vector_type(4)));
-    const u4_t* gh = (const u4_t*)(Hq + (size_t)by * nks * 6 * 128 * 16) + tid;
+    // A operand (h): complex64 rows [Mpad][lda], zero padded to the tile and to Kpad, split into its fp16 planes HERE, on the way into
+    // LDS (8 B per element from memory instead of 12 B of planes, and no packing pass over the right-hand sides): thread (row tid >> 1,
+    // half tid & 1) fetches its 8 complex values of a stage = 64 B; two threads cover 128 contiguous bytes of a row
+    const u4_t* gh = (const u4_t*)(Hf + (size_t)(m0 + (tid >> 1)) * lda + (tid & 1) * 8);
     const u4_t* gw = (const u4_t*)(Wq + (size_t)bx * nks * 6 * 128 * 16) + tid;
+    const float sh = h2_scale(__uint_as_float(amax[1]));
     const unsigned st_off = (unsigned)((tid >> 1) * H2_ROWB + (tid & 1) * 16);
     // fragment of a 32-row tile: lane l holds row (l & 31), k = 8 (l >> 5) ... + 7: one 16-B read
     const unsigned fr_off = (unsigned)((lane & 31) * H2_ROWB + (lane >> 5) * 16);
@@ -277,13 +281,26 @@ cgemm_w_kernel_h2(int P, int Kpad, int M, int ldo, const _Float16* __restrict__ 
 #define H2_FETCH(R, ks)                                                                                                   \
     do {                                                                                                                  \
         const int ks_ = (ks) < nks ? (ks) : nks - 1;             /* (past the end: re-read the last stage, no branch) */    \
-        const u4_t* a_ = gh + (size_t)ks_ * 1536; const u4_t* b_ = gw + (size_t)ks_ * 1536;                                 \
-        _Pragma("unroll") for (int q_ = 0; q_ < 6; ++q_) { R[q_] = a_[q_ * 256]; R[6 + q_] = b_[q_ * 256]; }                \
+        const u4_t* a_ = gh + (size_t)ks_ * 8; const u4_t* b_ = gw + (size_t)ks_ * 1536;     /* a stage = 16 complex = 8 x 16 B of a row */ \
+        _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) R[q_] = a_[q_];                                                   \
+        _Pragma("unroll") for (int q_ = 0; q_ < 6; ++q_) R[6 + q_] = b_[q_ * 256];                                         \
     } while (0)
 #define H2_STAGE(R, buf)                                                                                                  \
     do {                                                                                                                  \
         unsigned char* Hs_ = lds_raw + (size_t)(buf) * 2 * 6 * H2_PLANE + st_off; unsigned char* Ws_ = Hs_ + 6 * H2_PLANE;  \
-        _Pragma("unroll") for (int q_ = 0; q_ < 6; ++q_) { *(u4_t*)(Hs_ + q_ * H2_PLANE) = R[q_]; *(u4_t*)(Ws_ + q_ * H2_PLANE) = R[6 + q_]; } \
+        h8_t pl_[6];                                                                                                      \
+        _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {                                                                \
+            const float c_[2][3] = {{__uint_as_float(R[q_].x) * sh, __uint_as_float(R[q_].y) * sh, 0.f},                    \
+                                    {__uint_as_float(R[q_].z) * sh, __uint_as_float(R[q_].w) * sh, 0.f}};                   \
+            _Pragma("unroll") for (int e_ = 0; e_ < 2; ++e_) {                                                            \
+                const float v_[3] = {c_[e_][0], c_[e_][1], c_[e_][0] + c_[e_][1]};                                         \
+                _Pragma("unroll") for (int z_ = 0; z_ < 3; ++z_) {                                                        \
+                    const _Float16 hi_ = (_Float16)v_[z_];                                                                \
+                    pl_[2 * z_][2 * q_ + e_] = hi_; pl_[2 * z_ + 1][2 * q_ + e_] = (_Float16)(v_[z_] - (float)hi_);        \
+                }                                                                                                         \
+            }                                                                                                             \
+        }                                                                                                                 \
+        _Pragma("unroll") for (int q_ = 0; q_ < 6; ++q_) { *(h8_t*)(Hs_ + q_ * H2_PLANE) = pl_[q_]; *(u4_t*)(Ws_ + q_ * H2_PLANE) = R[6 + q_]; } \
     } while (0)
     // One wave per SIMD: nothing but this wave's own instruction order hides latencies.  The fragments of a real product are read from
     // LDS one product AHEAD of the MFMAs that use them (two fragment sets), the next stage's global loads are issued at the top of a
@@ -317,14 +334,14 @@ cgemm_w_kernel_h2(int P, int Kpad, int M, int ldo, const _Float16* __restrict__ 
     H2_FRAGS(0, 0, 0);
     for (int t = 0; t < nks; ++t) {
         const int buf = t & 1;
-        // region 1: the 12 global loads of stage t + 1 go out ONE PER MFMA of product 0 (issued in a block they cost the wave ~200
+        // region 1: the 10 global loads of stage t + 1 go out ONE PER MFMA of product 0 (issued in a block they cost the wave ~200
         // cycles in which its matrix pipe drains); product 1's fragments are read meanwhile
         H2_FRAGS(1, buf, 1);
         H2_FETCH(pa, t + 1);
         H2_MFMAS(0, 0);
         __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);       // 8 DS reads
 #pragma unroll
-        for (int i = 0; i < 12; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); }   // MFMA, VMEM read
+        for (int i = 0; i < 10; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); }   // MFMA, VMEM read (4 of h + 6 of W)
         __builtin_amdgcn_sched_barrier(0);
         // region 2: product 2's fragments, product 1's MFMAs
         H2_FRAGS(0, buf, 2);
@@ -597,8 +614,9 @@ int64_t chest_mmse_full_apply_scratch_bytes(int32_t P, int32_t num_grids) {
 
 // W h for M right-hand sides on the matrix pipe.  h_src [M][h_ld] complex64 (rows beyond M and columns beyond P are taken as zero).
 // Default: the fp16-split form (cgemm_w_kernel_h2); chest_tune "gemm_f32" 1: the exact-f32 3-multiplication kernel (A/B).
+// `Wpacked` != nullptr: the filter as chest_mmse_full_pack_filter left it (planes + its maximum); W is then not looked at.
 static int launch_w_gemm(chest_ctx* ctx, hipStream_t st, int P, int M, const float2* h_src, int h_ld, const float2* W, float* h_scratch,
-                         bool h_src_is_packed_f32) {
+                         bool h_src_is_packed_f32, const void* Wpacked = nullptr) {
     const int Ppad = pad16(P), Mpad = pad128(M), Npad = pad128(P);
     float2* h_in = (float2*)h_scratch;
     float2* h_out = h_in + (size_t)Mpad * Ppad;
@@ -606,6 +624,7 @@ static int launch_w_gemm(chest_ctx* ctx, hipStream_t st, int P, int M, const flo
     _Float16* Wq = Hq + (size_t)6 * Mpad * Ppad;
     unsigned* amax = (unsigned*)(Wq + (size_t)6 * Npad * Ppad);
     if (ctx->tune_gemm_f32) {
+        if (Wpacked != nullptr) { set_error("a packed filter is read by the fp16-split kernel only (chest_tune gemm_f32 is set)"); return CHEST_ESTATE; }
         float2* w_packed = (float2*)Wq;
         const float2* h_op = h_src;
         const int sp_pack = prof_open(ctx, st, CHEST_K_PACK);
@@ -620,17 +639,28 @@ static int launch_w_gemm(chest_ctx* ctx, hipStream_t st, int P, int M, const flo
         CHEST_HIP(hipGetLastError());
         return CHEST_OK;
     }
+    // the right-hand sides are read as they are if they already are a zero-padded [Mpad][Ppad] array (the frame kernel's h_ls_pilots at
+    // whole tiles, the gather of chest_mmse_full_apply); else they are copied into one first
     const int sp_pack = prof_open(ctx, st, CHEST_K_PACK);
+    const float2* h_op = h_src;
+    int h_op_ld = h_ld;
+    if (!h_src_is_packed_f32) { hipLaunchKernelGGL(pack_h_kernel, dim3(Mpad), dim3(256), 0, st, M, P, h_ld, Ppad, h_src, h_in); h_op = h_in; h_op_ld = Ppad; }
     CHEST_HIP(hipMemsetAsync(amax, 0, 64, st));
-    hipLaunchKernelGGL(absmax_kernel, dim3(256), dim3(256), 0, st, P, 2 * P, 2 * P, (const float*)W, amax);
-    hipLaunchKernelGGL(absmax_kernel, dim3(2048), dim3(256), 0, st, M, 2 * P, 2 * h_ld, (const float*)h_src, amax + 1);
-    hipLaunchKernelGGL(pack_h2_kernel, dim3(Npad / 128, (Ppad / 16 + H2_PACK_KS - 1) / H2_PACK_KS), dim3(256), 0, st, P, P, P, Ppad, W, amax, Wq);
-    hipLaunchKernelGGL(pack_h2_kernel, dim3(Mpad / 128, (Ppad / 16 + H2_PACK_KS - 1) / H2_PACK_KS), dim3(256), 0, st, M, P, h_ld, Ppad, h_src, amax + 1, Hq);
+    const _Float16* Wq_use = Wq;
+    if (Wpacked != nullptr) {
+        Wq_use = (const _Float16*)Wpacked;
+        // the packed filter carries its own maximum behind the planes: bring it next to the right-hand sides'
+        CHEST_HIP(hipMemcpyAsync(amax, (const unsigned char*)Wpacked + (size_t)12 * Npad * Ppad, sizeof(unsigned), hipMemcpyDeviceToDevice, st));
+    } else {
+        hipLaunchKernelGGL(absmax_kernel, dim3(256), dim3(256), 0, st, P, 2 * P, 2 * P, (const float*)W, amax);
+        hipLaunchKernelGGL(pack_h2_kernel, dim3(Npad / 128, (Ppad / 16 + H2_PACK_KS - 1) / H2_PACK_KS), dim3(256), 0, st, P, P, P, Ppad, W, amax, Wq);
+    }
+    hipLaunchKernelGGL(absmax_kernel, dim3(2048), dim3(256), 0, st, M, 2 * P, 2 * h_op_ld, (const float*)h_op, amax + 1);
     prof_close(ctx, st, sp_pack);
     CHEST_LDS_OPT_IN(ctx, LDS_GEMM, cgemm_w_kernel_h2, H2_LDS_BYTES);
     const int sp_gemm = prof_open(ctx, st, CHEST_K_GEMM);
     hipLaunchKernelGGL(cgemm_w_kernel_h2, dim3((((Npad / T2_N) * (Mpad / T2_M) + 7) / 8) * 8), dim3(256), H2_LDS_BYTES, st, P, Ppad, M, Ppad,
-                       (const _Float16*)Wq, (const _Float16*)Hq, (const unsigned*)amax, h_out);
+                       Wq_use, h_op, h_op_ld, (const unsigned*)amax, h_out);
     prof_close(ctx, st, sp_gemm);
     CHEST_HIP(hipGetLastError());
     return CHEST_OK;
@@ -701,6 +731,39 @@ int chest_mmse_full_filter_pilots(chest_ctx* ctx, void* stream, int32_t B, const
     const int Mpad = pad128(M);
     const bool h_in_place = h_ls_stride == Ppad && M == Mpad && ((uintptr_t)h_ls_pilots & 15) == 0;
     return launch_w_gemm(ctx, st, P, M, (const float2*)h_ls_pilots, h_ls_stride, (const float2*)W, h_scratch, h_in_place);
+}
+
+int64_t chest_mmse_full_packed_filter_bytes(int32_t P) {
+    if (P <= 0) return 0;
+    return (int64_t)12 * pad128(P) * pad16(P) + 64;             // six fp16 planes [Npad][Ppad] | the filter's largest magnitude
+}
+
+int chest_mmse_full_pack_filter(chest_ctx* ctx, void* stream, int32_t P, const float* W, void* packed) {
+    if (!ctx || P <= 0 || !W || !packed || ((uintptr_t)packed & 15) != 0) { set_error("chest_mmse_full_pack_filter: bad argument"); return CHEST_EINVAL; }
+    CHEST_GUARD(ctx);
+    hipStream_t st = (hipStream_t)stream;
+    const int Ppad = pad16(P), Npad = pad128(P);
+    unsigned* amax = (unsigned*)((unsigned char*)packed + (size_t)12 * Npad * Ppad);
+    CHEST_HIP(hipMemsetAsync(amax, 0, 64, st));
+    hipLaunchKernelGGL(absmax_kernel, dim3(256), dim3(256), 0, st, P, 2 * P, 2 * P, W, amax);
+    hipLaunchKernelGGL(pack_h2_kernel, dim3(Npad / 128, (Ppad / 16 + H2_PACK_KS - 1) / H2_PACK_KS), dim3(256), 0, st, P, P, P, Ppad,
+                       (const float2*)W, amax, (_Float16*)packed);
+    CHEST_HIP(hipGetLastError());
+    return CHEST_OK;
+}
+
+int chest_mmse_full_filter_pilots_packed(chest_ctx* ctx, void* stream, int32_t B, const float* h_ls_pilots, int32_t h_ls_stride,
+                                         int32_t slot, const void* packed_filter, float* h_scratch) {
+    int rc = full_pilots_check(ctx, "chest_mmse_full_filter_pilots_packed", B, slot, h_scratch);
+    if (rc != CHEST_OK || B == 0) return rc;
+    if (!h_ls_pilots || !packed_filter) { set_error("chest_mmse_full_filter_pilots_packed: bad argument"); return CHEST_EINVAL; }
+    CHEST_GUARD(ctx);
+    const auto& f = ctx->fp;
+    const PatternDev& pd = ctx->patterns[slot].dev;
+    const int P = pd.P, Ppad = pad16(P), M = B * f.R;
+    if (h_ls_stride < P) { set_error("h_ls_stride %d < %d pilots", h_ls_stride, P); return CHEST_EINVAL; }
+    const bool h_in_place = h_ls_stride == Ppad && M == pad128(M) && ((uintptr_t)h_ls_pilots & 15) == 0;
+    return launch_w_gemm(ctx, (hipStream_t)stream, P, M, (const float2*)h_ls_pilots, h_ls_stride, nullptr, h_scratch, h_in_place, packed_filter);
 }
 
 int chest_mmse_full_interp_pilots(chest_ctx* ctx, void* stream, int32_t B, int32_t slot, const float* h_scratch, float* H_est) {

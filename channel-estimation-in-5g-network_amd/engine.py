@@ -539,8 +539,8 @@ class Engine:
         if h.dim() != 3 or h.shape[1] != g.num_rx or h.shape[2] < P:
             raise ValueError(f"h_ls_pilots must be [B, {g.num_rx}, >= {P}]")
         self._zero_pads(h, P, pads_are_zero)
-        if tuple(W.shape) != (P, P):
-            raise ValueError(f"W must be [{P}, {P}] for this pattern")
+        if W.dtype != torch.uint8 and tuple(W.shape) != (P, P):
+            raise ValueError(f"W must be [{P}, {P}] for this pattern (or the result of mmse_full_pack_filter)")
         B = h.shape[0]
         need = N.lib().chest_mmse_full_apply_scratch_bytes(P, B * g.num_rx)
         own_scratch = scratch is None
@@ -553,12 +553,29 @@ class Engine:
             out = self.empty_c64(*shape)
         elif tuple(out.shape) != shape or out.dtype != torch.complex64 or not out.is_contiguous():
             raise ValueError("out must be a contiguous complex64 [B,S,R,T,nsc] tensor")
-        N.check(N.lib().chest_mmse_full_apply_pilots(self._h, self._stream(), B, h.data_ptr(), h.shape[2], int(slot),
-                                                     W.contiguous().data_ptr(), scratch.data_ptr(), out.data_ptr()),
-                "chest_mmse_full_apply_pilots")
+        if W.dtype == torch.uint8:                                       # packed once: the two stages, back to back
+            self.mmse_full_filter_pilots(h, slot, W, scratch, pads_are_zero=True)
+            self.mmse_full_interp_pilots(B, slot, scratch, out)
+        else:
+            N.check(N.lib().chest_mmse_full_apply_pilots(self._h, self._stream(), B, h.data_ptr(), h.shape[2], int(slot),
+                                                         W.contiguous().data_ptr(), scratch.data_ptr(), out.data_ptr()),
+                    "chest_mmse_full_apply_pilots")
         if own_scratch:
             torch.cuda.current_stream(self.device).synchronize()   # our scratch is freed on return
         return out
+
+    def mmse_full_pack_filter(self, W):
+        """W [P, P] complex64 -> the filter GEMM's operand format (fp16 planes), packed ONCE for every later
+        ``mmse_full_apply_pilots`` / ``mmse_full_filter_pilots`` call that is handed the result as ``W`` (a uint8 tensor)."""
+        Wc = self._c64(W)
+        if Wc.dim() != 2 or Wc.shape[0] != Wc.shape[1]:
+            raise ValueError("W must be a square [P, P] matrix")
+        P = int(Wc.shape[0])
+        packed = torch.empty(N.lib().chest_mmse_full_packed_filter_bytes(P), dtype=torch.uint8, device=self.device)
+        N.check(N.lib().chest_mmse_full_pack_filter(self._h, self._stream(), P, Wc.contiguous().data_ptr(), packed.data_ptr()),
+                "chest_mmse_full_pack_filter")
+        packed._chest_filter_P = P
+        return packed
 
     def mmse_full_filter_pilots(self, h_ls_pilots, slot, W, scratch, pads_are_zero=False):
         """Stage 1 of ``mmse_full_apply_pilots`` on the current stream: W h_ls for every (frame, rx) on the MFMA pipe; the
@@ -569,14 +586,22 @@ class Engine:
         if h.dim() != 3 or h.shape[1] != g.num_rx or h.shape[2] < P or not h.is_contiguous():
             raise ValueError(f"h_ls_pilots must be a contiguous [B, {g.num_rx}, >= {P}] tensor")
         self._zero_pads(h, P, pads_are_zero)
-        if tuple(W.shape) != (P, P) or not W.is_contiguous():
+        packed = W.dtype == torch.uint8                                  # mmse_full_pack_filter's result
+        if packed:
+            if getattr(W, "_chest_filter_P", None) != P or W.numel() != N.lib().chest_mmse_full_packed_filter_bytes(P):
+                raise ValueError(f"the packed filter was not made for {P} pilots")
+        elif tuple(W.shape) != (P, P) or not W.is_contiguous():
             raise ValueError(f"W must be a contiguous [{P}, {P}] tensor for this pattern")
         B = h.shape[0]
         need = N.lib().chest_mmse_full_apply_scratch_bytes(P, B * g.num_rx)
         if scratch.numel() * scratch.element_size() < need:
             raise ValueError(f"scratch holds {scratch.numel() * scratch.element_size()} B, {need} B needed")
-        N.check(N.lib().chest_mmse_full_filter_pilots(self._h, self._stream(), B, h.data_ptr(), h.shape[2], int(slot), W.data_ptr(),
-                                                      scratch.data_ptr()), "chest_mmse_full_filter_pilots")
+        if packed:
+            N.check(N.lib().chest_mmse_full_filter_pilots_packed(self._h, self._stream(), B, h.data_ptr(), h.shape[2], int(slot),
+                                                                 W.data_ptr(), scratch.data_ptr()), "chest_mmse_full_filter_pilots_packed")
+        else:
+            N.check(N.lib().chest_mmse_full_filter_pilots(self._h, self._stream(), B, h.data_ptr(), h.shape[2], int(slot), W.data_ptr(),
+                                                          scratch.data_ptr()), "chest_mmse_full_filter_pilots")
 
     def mmse_full_interp_pilots(self, num_frames, slot, scratch, out):
         """Stage 2 on the current stream: interpolation of the filtered pilot values in ``scratch`` + T-fold stores into

@@ -355,6 +355,15 @@ int chest_mmse_full_filter_pilots(chest_ctx* ctx, void* stream, int32_t num_fram
                                   int32_t h_ls_stride, int32_t pattern_slot, const float* W, float* h_scratch);
 int chest_mmse_full_interp_pilots(chest_ctx* ctx, void* stream, int32_t num_frames, int32_t pattern_slot,
                                   const float* h_scratch, float* H_est);
+/* The filter stage with W packed ONCE (W = R (R + sigma^2 I)^-1 belongs to a (pattern, sigma^2) pair, the right-hand sides to a batch):
+ * chest_mmse_full_pack_filter converts W [P][P] c64 into the operand format of the filter GEMM -- the real, imaginary and (re + im)
+ * parts of every entry as two fp16 terms each, scaled by a power of two, in the order the kernel stages them -- and
+ * chest_mmse_full_filter_pilots_packed reads that instead of packing W on every call.  Same results as chest_mmse_full_filter_pilots
+ * bit for bit (which packs into its scratch).  `packed`: chest_mmse_full_packed_filter_bytes(P) bytes, 16-B aligned, device. */
+int64_t chest_mmse_full_packed_filter_bytes(int32_t num_pilots);
+int chest_mmse_full_pack_filter(chest_ctx* ctx, void* stream, int32_t num_pilots, const float* W, void* packed);
+int chest_mmse_full_filter_pilots_packed(chest_ctx* ctx, void* stream, int32_t num_frames, const float* h_ls_pilots,
+                                         int32_t h_ls_stride, int32_t pattern_slot, const void* packed_filter, float* h_scratch);
 
 /* Dense Clough-Tocher ('cubic') operator of a pattern, built ON THE DEVICE from a triangulation (griddata(method='cubic') =
  * scipy.interpolate.CloughTocher2DInterpolator, reached through src/baseline_estimators.py:65-79): global gradient

@@ -372,3 +372,24 @@ def test_full_covariance_filter_on_the_fp16_pipe_is_float32_accurate():
         assert errs[0] < 5e-6 and errs[1] < 5e-6, (snr, hscale, errs)
         assert errs[0] < 2.0 * errs[1] + 1e-6, (snr, hscale, errs)        # no worse than the f32 kernel
     eng.close()
+
+
+def test_packed_filter_equals_per_call_packing():
+    """chest_mmse_full_pack_filter + chest_mmse_full_filter_pilots_packed (W packed once, outside the batch loop) give the bits of
+    chest_mmse_full_apply_pilots, which packs W into its scratch on every call."""
+    geom = E.Geometry(fft_size=1024, cp_length=72, num_symbols=14, useful_subcarriers=72, num_tx=2, num_rx=2)
+    eng = E.Engine(geom, 0)
+    rs = np.random.RandomState(3)
+    P = 99
+    pil = np.sort(rs.permutation(geom.grid)[:P])
+    slot = eng.pattern_slot(pil, "linear")
+    A = rs.randn(P, P) + 1j * rs.randn(P, P)
+    W = eng.mmse_full_prepare(A @ A.conj().T / P + np.eye(P), 12.0)
+    hls = eng.run_frames(E.make_descs("EVA", 70.0, 12.0, slot, n=70), seed=5, outputs=("h_ls_pilots",))["h_ls_pilots"]
+    want = eng.mmse_full_apply_pilots(hls, slot, W, pads_are_zero=True)
+    Wp = eng.mmse_full_pack_filter(W)
+    got = eng.mmse_full_apply_pilots(hls, slot, Wp, pads_are_zero=True)
+    assert torch.equal(got, want)
+    with pytest.raises(ValueError):
+        eng.mmse_full_apply_pilots(hls, slot, eng.mmse_full_pack_filter(W[:50, :50].contiguous()))
+    eng.close()
