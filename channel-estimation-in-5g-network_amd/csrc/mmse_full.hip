@@ -243,7 +243,7 @@ pack_h2_kernel(int nr, int P, int ld, int Kpad, const float2* __restrict__ X, co
 // in cgemm_w_kernel_3m: the epilogue is the same), ONE workgroup per CU (147 KB of LDS, up to 512 registers per lane).
 __global__ void __launch_bounds__(256, 1)
 cgemm_w_kernel_h2(int P, int Kpad, int M, int ldo, const _Float16* __restrict__ Wq, const float2* __restrict__ Hf, int lda,
-                  const unsigned* __restrict__ amax, float2* __restrict__ Hout) {
+                  const unsigned* __restrict__ amax_w, const unsigned* __restrict__ amax_h, float2* __restrict__ Hout) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     // Tile order: workgroups are dealt round-robin to the 8 XCDs; each XCD walks a contiguous run of tiles in i-major order, so the
@@ -273,7 +273,7 @@ cgemm_w_kernel_h2(int P, int Kpad, int M, int ldo, const _Float16* __restrict__ 
     // half tid & 1) fetches its 8 complex values of a stage = 64 B; two threads cover 128 contiguous bytes of a row
     const u4_t* gh = (const u4_t*)(Hf + (size_t)(m0 + (tid >> 1)) * lda + (tid & 1) * 8);
     const u4_t* gw = (const u4_t*)(Wq + (size_t)bx * nks * 6 * 128 * 16) + tid;
-    const float sh = h2_scale(__uint_as_float(amax[1]));
+    const float sh = h2_scale(__uint_as_float(*amax_h));
     const unsigned st_off = (unsigned)((tid >> 1) * H2_ROWB + (tid & 1) * 16);
     // fragment of a 32-row tile: lane l holds row (l & 31), k = 8 (l >> 5) ... + 7: one 16-B read
     const unsigned fr_off = (unsigned)((lane & 31) * H2_ROWB + (lane >> 5) * 16);
@@ -363,7 +363,7 @@ cgemm_w_kernel_h2(int P, int Kpad, int M, int ldo, const _Float16* __restrict__ 
 #undef H2_MFMAS
 #undef H2_FETCH
 #undef H2_STAGE
-    const float inv = 1.0f / (h2_scale(__uint_as_float(amax[0])) * h2_scale(__uint_as_float(amax[1])));     // exact: powers of two
+    const float inv = 1.0f / (h2_scale(__uint_as_float(*amax_w)) * sh);     // exact: powers of two
 #pragma unroll
     for (int x = 0; x < 2; ++x)
 #pragma unroll
@@ -647,10 +647,10 @@ static int launch_w_gemm(chest_ctx* ctx, hipStream_t st, int P, int M, const flo
     if (!h_src_is_packed_f32) { hipLaunchKernelGGL(pack_h_kernel, dim3(Mpad), dim3(256), 0, st, M, P, h_ld, Ppad, h_src, h_in); h_op = h_in; h_op_ld = Ppad; }
     CHEST_HIP(hipMemsetAsync(amax, 0, 64, st));
     const _Float16* Wq_use = Wq;
-    if (Wpacked != nullptr) {
+    const unsigned* amax_w = amax;
+    if (Wpacked != nullptr) {                                    // the packed filter carries its own maximum behind the planes
         Wq_use = (const _Float16*)Wpacked;
-        // the packed filter carries its own maximum behind the planes: bring it next to the right-hand sides'
-        CHEST_HIP(hipMemcpyAsync(amax, (const unsigned char*)Wpacked + (size_t)12 * Npad * Ppad, sizeof(unsigned), hipMemcpyDeviceToDevice, st));
+        amax_w = (const unsigned*)((const unsigned char*)Wpacked + (size_t)12 * Npad * Ppad);
     } else {
         hipLaunchKernelGGL(absmax_kernel, dim3(256), dim3(256), 0, st, P, 2 * P, 2 * P, (const float*)W, amax);
         hipLaunchKernelGGL(pack_h2_kernel, dim3(Npad / 128, (Ppad / 16 + H2_PACK_KS - 1) / H2_PACK_KS), dim3(256), 0, st, P, P, P, Ppad, W, amax, Wq);
@@ -660,7 +660,7 @@ static int launch_w_gemm(chest_ctx* ctx, hipStream_t st, int P, int M, const flo
     CHEST_LDS_OPT_IN(ctx, LDS_GEMM, cgemm_w_kernel_h2, H2_LDS_BYTES);
     const int sp_gemm = prof_open(ctx, st, CHEST_K_GEMM);
     hipLaunchKernelGGL(cgemm_w_kernel_h2, dim3((((Npad / T2_N) * (Mpad / T2_M) + 7) / 8) * 8), dim3(256), H2_LDS_BYTES, st, P, Ppad, M, Ppad,
-                       Wq_use, h_op, h_op_ld, (const unsigned*)amax, h_out);
+                       Wq_use, h_op, h_op_ld, amax_w, (const unsigned*)(amax + 1), h_out);
     prof_close(ctx, st, sp_gemm);
     CHEST_HIP(hipGetLastError());
     return CHEST_OK;
