@@ -182,20 +182,22 @@ __device__ __forceinline__ float h2_scale(float amax) {
     return ldexpf(1.0f, 14 - e);
 }
 
-// largest |x[r][c]|, c < cols, of a [rows][ld] float array (pad columns beyond cols are not looked at; ld and cols multiples of 4,
-// rows 16-B aligned): one row per pass of a workgroup, float4 loads
+// largest |x[i]| of a contiguous, 16-B aligned float array (pad entries inside it are zeros): eight float4 loads in flight per thread
 __global__ void __launch_bounds__(256)
-absmax_kernel(int rows, int cols, int ld, const float* __restrict__ x, unsigned* __restrict__ out) {
+absmax_kernel(size_t n, const float* __restrict__ x, unsigned* __restrict__ out) {
     float m = 0.f;
-    for (int r = blockIdx.x; r < rows; r += gridDim.x) {
-        const float* xr = x + (size_t)r * ld;
-        const int c4 = (((uintptr_t)xr & 15) == 0) ? cols >> 2 : 0;          // float4 loads where the row starts on a 16-B boundary
-        for (int c = threadIdx.x; c < c4; c += blockDim.x) {
-            const float4 v = ((const float4*)xr)[c];
-            m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));      // (fmaxf drops a NaN; the GEMM propagates it)
-        }
-        for (int c = (c4 << 2) + threadIdx.x; c < cols; c += blockDim.x) m = fmaxf(m, fabsf(xr[c]));
+    const size_t n4 = n >> 2, stride = (size_t)gridDim.x * blockDim.x;
+    const float4* x4 = (const float4*)x;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + 7 * stride < n4; i += 8 * stride) {
+        float4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = x4[i + u * stride];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) m = fmaxf(m, fmaxf(fmaxf(fabsf(v[u].x), fabsf(v[u].y)), fmaxf(fabsf(v[u].z), fabsf(v[u].w))));   // (fmaxf drops a NaN; the GEMM propagates it)
     }
+    for (; i < n4; i += stride) { const float4 v = x4[i]; m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)))); }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) m = fmaxf(m, fabsf(x[(n4 << 2) + threadIdx.x]));
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
     if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(out, __float_as_uint(m));      // non-negative floats order like their bit patterns
@@ -646,16 +648,17 @@ static int launch_w_gemm(chest_ctx* ctx, hipStream_t st, int P, int M, const flo
     int h_op_ld = h_ld;
     if (!h_src_is_packed_f32) { hipLaunchKernelGGL(pack_h_kernel, dim3(Mpad), dim3(256), 0, st, M, P, h_ld, Ppad, h_src, h_in); h_op = h_in; h_op_ld = Ppad; }
     CHEST_HIP(hipMemsetAsync(amax, 0, 64, st));
+    if (Wpacked == nullptr && ((uintptr_t)W & 15) != 0) { set_error("W must be a 16-byte aligned device pointer"); return CHEST_EINVAL; }
     const _Float16* Wq_use = Wq;
     const unsigned* amax_w = amax;
     if (Wpacked != nullptr) {                                    // the packed filter carries its own maximum behind the planes
         Wq_use = (const _Float16*)Wpacked;
         amax_w = (const unsigned*)((const unsigned char*)Wpacked + (size_t)12 * Npad * Ppad);
     } else {
-        hipLaunchKernelGGL(absmax_kernel, dim3(256), dim3(256), 0, st, P, 2 * P, 2 * P, (const float*)W, amax);
+        hipLaunchKernelGGL(absmax_kernel, dim3(256), dim3(256), 0, st, (size_t)2 * P * P, (const float*)W, amax);
         hipLaunchKernelGGL(pack_h2_kernel, dim3(Npad / 128, (Ppad / 16 + H2_PACK_KS - 1) / H2_PACK_KS), dim3(256), 0, st, P, P, P, Ppad, W, amax, Wq);
     }
-    hipLaunchKernelGGL(absmax_kernel, dim3(2048), dim3(256), 0, st, M, 2 * P, 2 * h_op_ld, (const float*)h_op, amax + 1);
+    hipLaunchKernelGGL(absmax_kernel, dim3(1024), dim3(256), 0, st, (size_t)2 * M * h_op_ld, (const float*)h_op, amax + 1);   // (zero pads inside)
     prof_close(ctx, st, sp_pack);
     CHEST_LDS_OPT_IN(ctx, LDS_GEMM, cgemm_w_kernel_h2, H2_LDS_BYTES);
     const int sp_gemm = prof_open(ctx, st, CHEST_K_GEMM);
@@ -739,13 +742,16 @@ int64_t chest_mmse_full_packed_filter_bytes(int32_t P) {
 }
 
 int chest_mmse_full_pack_filter(chest_ctx* ctx, void* stream, int32_t P, const float* W, void* packed) {
-    if (!ctx || P <= 0 || !W || !packed || ((uintptr_t)packed & 15) != 0) { set_error("chest_mmse_full_pack_filter: bad argument"); return CHEST_EINVAL; }
+    if (!ctx || P <= 0 || !W || !packed || ((uintptr_t)packed & 15) != 0 || ((uintptr_t)W & 15) != 0) {
+        set_error("chest_mmse_full_pack_filter: bad argument (W and packed must be 16-byte aligned device pointers)");
+        return CHEST_EINVAL;
+    }
     CHEST_GUARD(ctx);
     hipStream_t st = (hipStream_t)stream;
     const int Ppad = pad16(P), Npad = pad128(P);
     unsigned* amax = (unsigned*)((unsigned char*)packed + (size_t)12 * Npad * Ppad);
     CHEST_HIP(hipMemsetAsync(amax, 0, 64, st));
-    hipLaunchKernelGGL(absmax_kernel, dim3(256), dim3(256), 0, st, P, 2 * P, 2 * P, W, amax);
+    hipLaunchKernelGGL(absmax_kernel, dim3(256), dim3(256), 0, st, (size_t)2 * P * P, W, amax);
     hipLaunchKernelGGL(pack_h2_kernel, dim3(Npad / 128, (Ppad / 16 + H2_PACK_KS - 1) / H2_PACK_KS), dim3(256), 0, st, P, P, P, Ppad,
                        (const float2*)W, amax, (_Float16*)packed);
     CHEST_HIP(hipGetLastError());

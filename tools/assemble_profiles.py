@@ -19,7 +19,7 @@ def newest(pattern):
     return max(files, key=os.path.getmtime) if files else None
 
 
-def chest_rows(src, dst, keep=("chest::",)):
+def chest_rows(src, dst, keep=("chest::", "_ZN5chest")):
     """rows of the library's kernels only (a bench process also runs torch fills and copies)"""
     with open(src) as f, open(dst, "w", newline="") as g:
         r = csv.DictReader(f)
@@ -50,7 +50,7 @@ def timed_region_stats(trace_csv, bench_json, out_csv):
     with open(trace_csv) as f:
         for row in csv.DictReader(f):
             k = row["Kernel_Name"]
-            if "chest::" in k:
+            if "chest::" in k or "_ZN5chest" in k:       # (rocprofv3 leaves names with _Float16 parameters mangled)
                 per.setdefault(k[:100], []).append((int(row["Start_Timestamp"]), int(row["End_Timestamp"]) - int(row["Start_Timestamp"])))
     with open(out_csv, "w", newline="") as g:
         w = csv.writer(g)
