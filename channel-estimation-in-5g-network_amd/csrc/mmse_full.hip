@@ -179,7 +179,9 @@ __device__ __forceinline__ float h2_scale(float amax) {
     if (!(amax > 0.f)) return 1.0f;
     int e;
     (void)frexpf(2.0f * amax, &e);                           // 2 amax = m 2^e, 0.5 <= m < 1
-    return ldexpf(1.0f, 14 - e);
+    e = 14 - e;
+    e = e > 60 ? 60 : (e < -60 ? -60 : e);                   // (operands of subnormal size or near the float maximum: the product of the two
+    return ldexpf(1.0f, e);                                  //  scales and its reciprocal stay finite; such operands lose precision, not sign)
 }
 
 // largest |x[i]| of a contiguous, 16-B aligned float array (pad entries inside it are zeros): eight float4 loads in flight per thread
