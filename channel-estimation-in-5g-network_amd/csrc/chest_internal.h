@@ -89,6 +89,7 @@ struct chest_ctx {
     int32_t tune_rx_group = 0;            // rx antennas per slab unit of the frame kernel (0 = chosen from the LDS budget)
     int32_t tune_taps_threads = 0;        // taps kernel workgroup size 64 / 128 / 256 (0 = by antenna count)
     int32_t tune_gemm_f32 = 0;            // 1: the full-covariance filter on the exact-f32 MFMA kernel (cgemm_w_kernel_3m) instead of the fp16-split one (A/B)
+    int32_t tune_two_slabs = 0;           // -1: no second slab for the one-workgroup-per-CU frame kernel (A/B)
     int32_t tune_store_extra = 0;         // dedicated store waves per frame workgroup (0 = the default of the launcher, -1 = none); experiments
     int32_t tune_store_waves = 0;         // waves of a frame workgroup that stream the slab out (0 = the rule in slab_body); experiments
     int32_t tune_min_waves = 0;           // 4 = the 128-VGPR instantiation of the 2x2 frame kernel (two workgroups per CU), for A/B

@@ -99,6 +99,7 @@ struct SlabArgs {
     float* alpha;
     float2* slab;      // LDS, 16-B aligned
     RngKey key;
+    int slab2;         // float2 elements from `slab` to a SECOND slab (0: none): synthesis units alternate between the two (see slab_body)
     int b, RG, nst, nsx;    // nsx: dedicated store waves at the end of the workgroup; nst: store-out crew override (chest_tune "frame_store_waves", experiments), 0 = by the rule in slab_body
 };
 
@@ -209,6 +210,12 @@ __device__ __forceinline__ void slab_body(const SlabArgs& A) {
     const int seg_tx = 0, seg_h = slab_seg(txr, nsc), seg_rx = seg_h + slab_seg(SSN * RG * T, nsc);
     const int ngroups = R / RG;
     bool first_unit = true;
+    // Two slabs (launches whose LDS has room: the 2048-FFT 4x4 frames without estimates, 2 x 67 KB) with dedicated store waves: unit
+    // u + 1 is synthesised and written into the OTHER slab while the store waves stream unit u -- the barrier in front of the slab
+    // writes ("the previous store-out has read the slab") goes away, one barrier per unit is left, and the workgroup's store stream
+    // no longer pauses for the synthesis (one workgroup per CU: nothing else on the CU fills that pause).
+    const bool two_slabs = A.slab2 != 0 && nsx > 0;
+    int unit_no = 0;
     // Store-out crew.  A workgroup of 4n+1 waves puts two of its waves on one SIMD; the younger of them loses the issue
     // arbitration and is the straggler of every compute stretch (stamps: +40 % on the 5th wave).  It is excused from the
     // store-out: after the "slab complete" barrier it goes straight to the next unit's compute while the others stream the
@@ -275,9 +282,11 @@ __device__ __forceinline__ void slab_body(const SlabArgs& A) {
             // global spans of this unit (element offsets inside the frame) and their parities
             const unsigned e_tx = (unsigned)(sb * T) * (unsigned)nsc, e_h = (unsigned)((sb * R + r0) * T) * (unsigned)nsc,
                            e_rx = (unsigned)(sb * R + r0) * (unsigned)nsc;
-            float2* __restrict__ l_tx = slab + seg_tx + ((par_tx + e_tx) & 1);
-            float2* __restrict__ l_h = slab + seg_h + ((par_h + e_h) & 1);
-            float2* __restrict__ l_rx = slab + seg_rx + ((par_rx + e_rx) & 1);
+            float2* __restrict__ slab_u = slab + ((two_slabs && (unit_no & 1)) ? A.slab2 : 0);
+            ++unit_no;
+            float2* __restrict__ l_tx = slab_u + seg_tx + ((par_tx + e_tx) & 1);
+            float2* __restrict__ l_h = slab_u + seg_h + ((par_h + e_h) & 1);
+            float2* __restrict__ l_rx = slab_u + seg_rx + ((par_rx + e_rx) & 1);
             if constexpr (STAGED) {
                 // compute the whole unit into registers first: nothing here touches the slab, so this stretch overlaps the
                 // other waves' store-out of the previous unit
@@ -328,7 +337,7 @@ __device__ __forceinline__ void slab_body(const SlabArgs& A) {
                 }
                 }
                 STAMP_ADD(0);                                                    // W compute
-                if (!first_unit) __syncthreads();                                // previous unit's store-out has read the slab
+                if (!first_unit && !two_slabs) __syncthreads();                  // previous unit's store-out has read the slab
                 first_unit = false;
                 STAMP_ADD(1);                                                    // W barrier B
                 if (act) {
@@ -358,7 +367,7 @@ __device__ __forceinline__ void slab_body(const SlabArgs& A) {
                 const unsigned s0 = sc[0][0], s1 = sc[0][1];
                 const bool p0 = pp[0][0], p1 = pp[0][1];
                 const float2* __restrict__ cs = A.c_g + (size_t)s * KTS * R * T;     // this symbol's gains [tap][r][t]
-                if (!first_unit) __syncthreads();                                // previous unit's store-out has read the slab
+                if (!first_unit && !two_slabs) __syncthreads();                  // previous unit's store-out has read the slab
                 first_unit = false;
                 if (act && rg == 0 && txb != nullptr) {
                     for (int t = 0; t < txr; ++t) put(l_tx + t * nsc, x0, x1);
@@ -457,6 +466,12 @@ __device__ __forceinline__ void slab_body(const SlabArgs& A) {
             for (int i = tid; i < R * npad; i += blockDim.x) hl[(size_t)(i / npad) * out.h_ls_stride + P + i % npad] = make_float2(0.f, 0.f);
         }
     }
+#ifdef CHEST_STAMPS
+    if (!want_est && g_stamp_buf != nullptr && lane == 0) {      // (a launch without estimates leaves here: its stamps too)
+        unsigned long long* dst = g_stamp_buf + ((size_t)b * 16 + wave) * 16;
+        for (int i = 0; i < 12; ++i) dst[i] = st_sum[i];
+    }
+#endif
     if (!want_est) return;
 
     // ---- MMSE shrinkage per rx: p = mean|h_ls|^2, alpha = p/(p+sigma^2) (:177-190, scalar form) ---
@@ -739,7 +754,9 @@ frame_slab_kernel(const FrameParams* __restrict__ fpp, const chest_frame_desc* _
     A.slab = (float2*)(A.alpha + 8);                             // 16-B aligned: hp span is a multiple of 16 B, 40 floats = 160 B
     const uint64_t frame = frame_offset + (uint64_t)b;
     A.key = RngKey{(uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)frame, (uint32_t)(frame >> 32)};
-    A.b = b; A.RG = RG & 0xFF; A.nst = (RG >> 8) & 0xFF; A.nsx = RG >> 16;
+    A.b = b; A.RG = RG & 0xFF; A.nst = (RG >> 8) & 0xFF; A.nsx = (RG >> 16) & 0xFF;
+    // a second slab behind the first when the launch was given the LDS for it (bit 24 of the crew argument) and produces no estimates
+    A.slab2 = ((RG >> 24) & 1) && !want_est ? (slab_elems(T, RG & 0xFF, fp.nsc, SS, false) + 1) & ~1 : 0;
     switch (A.prof->ntaps) {                                     // workgroup-uniform dispatch on the profile
         case 5: slab_body<5, TT, RR, RGT, SS, INJ, CP>(A); break;         // EPA at 15.36 MHz
         case 8: slab_body<8, TT, RR, RGT, SS, INJ, CP>(A); break;         // EVA
@@ -803,7 +820,7 @@ int launch_k2_slab(chest_ctx* ctx, hipStream_t st, int32_t B, const chest_frame_
     int nsx = ctx->tune_store_extra != 0 ? (ctx->tune_store_extra < 0 ? 0 : ctx->tune_store_extra) : ((fp.T * fp.R >= 16 && nwave <= 5) ? 2 : 0);
     if (nsx > 2) nsx = 2;                                       // (the instantiations' launch bounds leave room for two)
     if (nwave + nsx > 16) nsx = 0;
-    const int RGarg = RG | (ctx->tune_store_waves << 8) | (nsx << 16);   // (crew parameters ride in the high bits of the kernel argument)
+
     const int T = fp.T, R = fp.R;
     const bool injected = inj.u_sym || inj.u_angle || inj.n_re;         // parity / replay mode: the generic instantiations
     // SISO frames have three rows per symbol: two symbols per unit halve the per-unit synchronisation (the spans of
@@ -815,8 +832,16 @@ int launch_k2_slab(chest_ctx* ctx, hipStream_t st, int32_t B, const chest_frame_
     const bool siso = !injected && !(fp.half & 1) && nwave <= 5 && T == 1 && R == 1 && RG == 1;
     // a launch without estimates (H_ls / H_mmse / metrics) keeps neither the pilot table nor the estimate segments in LDS
     const bool want_est = out.H_ls != nullptr || out.H_mmse != nullptr || out.metrics != nullptr;
-    const size_t lds = slab_lds_bytes(fp.nsc, fp.T, fp.R, RG, Pmax, siso ? SS_SISO : 1, want_est);
+    size_t lds = slab_lds_bytes(fp.nsc, fp.T, fp.R, RG, Pmax, siso ? SS_SISO : 1, want_est);
+    // One workgroup per CU (more than 80 KB... or 10 waves) and no estimates: a SECOND slab + two dedicated store waves let the store
+    // stream of unit u run beside the synthesis of unit u + 1 (slab_body).  chest_tune "frame_two_slabs" -1 switches it off (A/B).
+    bool two_slabs = false;
+    if (!want_est && !injected && nwave == 10 && fp.T == 4 && fp.R == 4 && RG == 1 && ctx->tune_two_slabs >= 0 && ctx->tune_store_extra >= 0) {
+        const size_t extra = (size_t)((slab_elems(fp.T, RG, fp.nsc, 1, false) + 1) & ~1) * sizeof(float2);
+        if (lds + extra <= 160 * 1024) { lds += extra; two_slabs = true; nsx = ctx->tune_store_extra > 0 ? (ctx->tune_store_extra > 4 ? 4 : ctx->tune_store_extra) : 2; }
+    }
     if (lds > 160 * 1024) { set_error("frame kernel needs %zu B of LDS (> 160 KiB): too many antennas, subcarriers or pilots", lds); return CHEST_EINVAL; }
+    const int RGarg = RG | (ctx->tune_store_waves << 8) | (nsx << 16) | ((two_slabs ? 1 : 0) << 24);   // (crew parameters ride in the high bits of the kernel argument)
     const dim3 grid((unsigned)B), block((unsigned)(nwave + nsx) * 64);
 #define CHEST_SLAB_ARGS st, grid, block, lds, descs, Pmax, seed, frame_offset, inj, out, workspace, RGarg
     if (compact) {
@@ -848,7 +873,7 @@ int launch_k2_slab(chest_ctx* ctx, hipStream_t st, int32_t B, const chest_frame_
         //  instantiation (five waves per SIMD).  Built and measured in round 4: 54 spilled registers, 2.00 against 1.90 ms per
         //  2 304 frames, 4.23 against 4.01 per 4 608 -- the synthesis is bound by the instructions it issues, not by residency;
         //  profiles/r04_cfg5_frame_kernel_isa.txt.  Not kept.)
-        if (!injected && !(fp.half & 1) && T == 4 && R == 4 && RG == 1) return launch_one<768, 3, 4, 4, 1, 1, false>(ctx, LDS_FRAME_640_44, CHEST_SLAB_ARGS);
+        if (!injected && !(fp.half & 1) && T == 4 && R == 4 && RG == 1) return launch_one<896, 4, 4, 4, 1, 1, false>(ctx, LDS_FRAME_640_44, CHEST_SLAB_ARGS);   // (10 compute + up to 4 store waves, <= 128 VGPRs)
         return launch_one<768, 3, 0, 0, 0, 1, true>(ctx, LDS_FRAME_640, CHEST_SLAB_ARGS);
     }
     return launch_one<1024, 4, 0, 0, 0, 1, true>(ctx, LDS_FRAME_1024, CHEST_SLAB_ARGS);

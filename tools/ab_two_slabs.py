@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""2048-FFT 4x4 frame kernel without estimates (config 5's launch, one workgroup per CU): one slab against two slabs + two dedicated
+store waves (chest_tune "frame_two_slabs" -1 / 0).  Frame kernel time from the library's HIP events, interleaved in one process on
+the same buffers; outputs compared bit for bit.  GPU only."""
+import importlib, os, sys
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+E = importlib.import_module("channel-estimation-in-5g-network_amd.engine")
+names = ("tx", "rx", "H", "pilot_symbols", "pilot_mask", "h_ls_pilots")
+geom = E.Geometry(fft_size=2048, cp_length=144, useful_subcarriers=1200, num_tx=4, num_rx=4)
+F = int(sys.argv[1]) if len(sys.argv) > 1 else 2304
+eng = E.Engine(geom, 0)
+slots = eng.build_patterns(0, [geom.grid // 10], seed=1, pattern_ids=np.arange(1, dtype=np.uint64), method="linear")
+d = torch.from_numpy(E.make_descs("ETU", 555.6, 10.0, int(slots[0]), n=F).view(np.uint8).copy()).to(eng.device)
+eng.tune("frame_two_slabs", -1)
+out = eng.run_frames(d, seed=3, outputs=names)
+ref = {k: out[k].clone() for k in names}
+res = {-1: [], 0: [], 1: [], 3: [], 4: []}
+for it in range(6):
+    for v in (-1, 0, 1, 3, 4):
+        eng.tune("frame_two_slabs", min(v, 0))
+        eng.tune("frame_store_extra", v if v > 0 else 0)
+        eng.profile_begin(1)
+        eng.run_frames(d, seed=3, frame_offset=0, outputs=names, out=out, check=False)
+        res[v].append(eng.profile_read()[1])
+        if it == 0:
+            for k in names:
+                assert os.environ.get("AB_NOCHECK") or torch.equal(ref[k], out[k]), (v, k)
+eng.check_status()
+print(f"2048-FFT 4x4, {F} frames, no estimates: one slab {np.median(res[-1][1:]):.3f} ms   two slabs + 2 store waves {np.median(res[0][1:]):.3f} ms   two slabs + 1 / 3 / 4 store waves {np.median(res[1][1:]):.3f} / {np.median(res[3][1:]):.3f} / {np.median(res[4][1:]):.3f} ms", flush=True)

@@ -23,8 +23,11 @@ def main():
     E = importlib.import_module(PKG + ".engine")
     N = importlib.import_module(PKG + "._native")
     F = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
-    geom = E.Geometry()
+    cfg5 = os.environ.get("STAMPS_SHAPE") == "cfg5"          # the 2048-FFT 4x4 launch of config 5 (no estimates; 10 compute waves + store waves)
+    geom = E.Geometry(fft_size=2048, cp_length=144, useful_subcarriers=1200, num_tx=4, num_rx=4) if cfg5 else E.Geometry()
     eng = E.Engine(geom, 0)
+    if os.environ.get("STAMPS_ONE_SLAB"):
+        eng.tune("frame_two_slabs", -1)
     eng.tune("frame_min_waves", int(sys.argv[2]) if len(sys.argv) > 2 else 0)
     G = geom.grid
     P = int(G * 0.1)
@@ -37,9 +40,9 @@ def main():
         for g in range((F + 1023) // 1024):
             perm = np.arange(G); np.random.RandomState(2024 + g).shuffle(perm)
             slots.append(eng.pattern_slot(np.sort(perm[:P]), "linear"))
-        descs = E.make_descs("EVA", 111.1, 10.0, np.asarray(slots, np.int32)[np.arange(F) // 1024], n=F)
+        descs = E.make_descs("ETU" if cfg5 else "EVA", 555.6 if cfg5 else 111.1, 10.0, np.asarray(slots, np.int32)[np.arange(F) // 1024], n=F)
     d_dev = torch.from_numpy(descs.view(np.uint8).copy()).to(eng.device)
-    names = ["tx", "rx", "H", "H_ls", "H_mmse", "pilot_symbols", "pilot_mask"]
+    names = ["tx", "rx", "H", "pilot_symbols", "pilot_mask", "h_ls_pilots"] if cfg5 else ["tx", "rx", "H", "H_ls", "H_mmse", "pilot_symbols", "pilot_mask"]
     out = eng.run_frames(d_dev, seed=1, outputs=names)
     buf = torch.zeros(F * 16 * 16, dtype=torch.int64, device=eng.device)
     lib = N.lib()
@@ -71,12 +74,13 @@ def main():
     conc = np.asarray(conc)
     print(f"CUs seen {len(conc)}; frames per CU {conc[:, 0].min():.0f}..{conc[:, 0].max():.0f}; peak resident workgroups per CU "
           f"{conc[:, 1].min():.0f}..{conc[:, 1].max():.0f}; time-averaged {conc[:, 2].mean():.2f}")
-    st = raw[:, :5, :12].astype(np.float64)       # 5 waves per workgroup
+    nw = 14 if cfg5 else 5
+    st = raw[:, :nw, :12].astype(np.float64)      # waves per workgroup (compute waves first, then any store waves)
     tot = st.sum(axis=2)
     print(f"stamped kernel {ms:.3f} ms; mean stamped cycles per wave per frame {tot.mean():,.0f}")
     for i, n in enumerate(NAMES):
         print(f"  {n:16s} {st[:, :, i].mean():10,.0f} cycles  {st[:, :, i].sum() / tot.sum():6.1%}   per wave: " +
-              " ".join(f"{st[:, w, i].mean():8,.0f}" for w in range(5)))
+              " ".join(f"{st[:, w, i].mean():8,.0f}" for w in range(nw)))
 
 
 if __name__ == "__main__":
