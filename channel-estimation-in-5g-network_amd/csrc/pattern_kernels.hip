@@ -34,7 +34,8 @@ namespace chest {
 #ifndef CHEST_PB_THREADS
 #define CHEST_PB_THREADS 256
 #endif
-constexpr int PB_THREADS = CHEST_PB_THREADS;      // >= 256 (the radix selection keeps its 256 bins on the first 256 threads)
+constexpr int PB_THREADS_DEFAULT = CHEST_PB_THREADS;      // >= 256 (the radix selection keeps its 256 bins on the first 256 threads)
+constexpr int PB_THREADS_NEAREST = 512;                   // 'nearest' plans: no flips, no serial stage -- eight waves per pattern (3.9 -> 5.3 M patterns/s)
 constexpr uint32_t TNONE = 0xFFFFu;
 constexpr int SEL_SHIFT = 20, SEL_BINS = 1 << (32 - SEL_SHIFT);      // pilot selection: histogram over the keys' top 12 bits
 constexpr int SEL_LIST = 256;                                        // capacity of the threshold bin's element list (mean G / 4096 <= 16)
@@ -115,6 +116,7 @@ __device__ __forceinline__ int count_pairsum_leq(const uint32_t* a, int n, int k
 
 // exclusive scan of one value per thread over the workgroup (wave shuffles + one LDS hop); `scr` >= 8 ints of LDS;
 // returns (exclusive prefix, total)
+template <int PB_THREADS>
 __device__ __forceinline__ int2 block_exscan(int v, int* scr) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int incl = v;
@@ -180,7 +182,7 @@ __device__ __forceinline__ void wave_balanced(uint32_t mask, int lane, F&& fn) {
     }
 }
 
-size_t pattern_build_lds_bytes(int G, int Pcap) {
+size_t pattern_build_lds_bytes(int G, int Pcap, int PB_THREADS = PB_THREADS_DEFAULT) {
     const size_t tri = (size_t)4 * Pcap + 16 + (size_t)2 * Pcap * (sizeof(uint16_t) * 6 + 4);            // pts | triangle records
     const size_t keys = (size_t)4 * (SEL_BINS + 2 * SEL_LIST);                                        // selection: histogram + threshold-bin list
     (void)G;
@@ -203,7 +205,7 @@ __device__ unsigned long long* g_pat_stamp = nullptr;           // [count][16]: 
 // P = 83: 1.05 -> 0.90); at P = 838 the LDS holds five either way and the kernel is bound by its vector instructions (r03 PMC:
 // 94 k VALU instructions per pattern, vector ALU 82 % busy) -- a 12-B packed record format that fits a sixth workgroup was
 // built, measured at the same 1.85-1.9 ms and dropped (profiles/r03_pattern_ab_formats.txt).
-template <bool COMPACT>
+template <bool COMPACT, int PB_THREADS>
 __global__ void __launch_bounds__(PB_THREADS, 8)
 pattern_build_kernel(const PatBuildArgs A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -280,7 +282,7 @@ pattern_build_kernel(const PatBuildArgs A) {
         constexpr int BPT = SEL_BINS / 256;                                    // bins per scanning thread
         int h = 0;
         if (tid < 256) for (int i = 0; i < BPT; ++i) h += (int)bins[tid * BPT + i];
-        const int2 ex = block_exscan(h, scan);                                 // keys in lower bin groups
+        const int2 ex = block_exscan<PB_THREADS>(h, scan);                                 // keys in lower bin groups
         if (tid < 256 && ex.x < P && P <= ex.x + h) {                          // exactly one group qualifies
             int acc = ex.x;
             for (int i = 0; i < BPT; ++i) {
@@ -327,7 +329,7 @@ pattern_build_kernel(const PatBuildArgs A) {
             if (ge >= 4 * q_lo && ge < 4 * q_hi && taken(lst[2 * e], ge)) { ++mine; m_take |= 1ull << ((ge - 4 * q_lo) & 63); }
         }
         (void)m_eq;
-        const int2 sp = block_exscan(mine, scan);
+        const int2 sp = block_exscan<PB_THREADS>(mine, scan);
         int pos = sp.x;
         if (masked) {
             for (uint64_t mm = m_take; mm != 0; mm &= mm - 1) pil[pos++] = 4 * q_lo + (__ffsll((long long)mm) - 1);
@@ -596,7 +598,7 @@ pattern_build_kernel(const PatBuildArgs A) {
     const int FLIP_SOLO_AT = A.solo_at > 0 ? A.solo_at : 192;      // (chest_tune "pattern_solo_at": experiments)
     const int lane = tid & 63, wave = tid >> 6, wbase = tid & ~63;
     const int round_cap = A.flip_cap > 0 ? A.flip_cap : 4 * NT + 64;
-    const bool can_solo = ntri <= 2048 && PB_THREADS == 256;
+    const bool can_solo = ntri <= 2048 && PB_THREADS >= 256;
     // [64] hand-over to stage 1 and its per-round set of claimed triangles (bit t >> 6 of word t & 63) -- in the row tables'
     // place, which are dead once the pockets are filled (the LDS granule is 1 280 B: 25 granules = 32 000 B per workgroup is
     // what lets five workgroups share a CU)
@@ -1023,8 +1025,8 @@ extern "C" int chest_patterns_build(chest_ctx* ctx, void* stream, int32_t first_
         }
         Pmax = num_pilots[i] > Pmax ? num_pilots[i] : Pmax;
     }
-    if (2 * Pmax > 32 * PB_THREADS) { set_error("chest_patterns_build: at most %d pilots per pattern", 16 * PB_THREADS); return CHEST_EINVAL; }
-    const size_t lds = pattern_build_lds_bytes(G, Pmax);
+    if (2 * Pmax > 32 * PB_THREADS_DEFAULT) { set_error("chest_patterns_build: at most %d pilots per pattern", 16 * PB_THREADS_DEFAULT); return CHEST_EINVAL; }
+    const size_t lds = pattern_build_lds_bytes(G, Pmax, method == 1 ? PB_THREADS_NEAREST : PB_THREADS_DEFAULT);
     if (lds > 160 * 1024) {
         set_error("chest_patterns_build: %d pilots need %zu B of LDS (> 160 KiB); use chest_pattern_set_triangulation for such patterns", Pmax, lds);
         return CHEST_EINVAL;
@@ -1102,14 +1104,20 @@ extern "C" int chest_patterns_build(chest_ctx* ctx, void* stream, int32_t first_
     a.simp_out = simplices_out; a.nbr_out = simplices_out ? neighbors_out : nullptr; a.nsimp_out = num_simplices_out; a.status = ctx->d_status;
     a.flip_cap = ctx->tune_pattern_flip_cap; a.stop_after = ctx->tune_pattern_stop_after; a.solo_at = ctx->tune_pattern_solo_at;
     if (simplices_out && pool->Pcap != Pmax) { set_error("chest_patterns_build: simplices_out needs a fresh slot range (row stride is 2*Pmax*3)"); return CHEST_EINVAL; }
-    const size_t lds_run = pattern_build_lds_bytes(G, pool->Pcap) + (size_t)ctx->tune_pattern_extra_lds;
+    // 'nearest' plans have no flips and no one-wave stage: their workgroups take eight waves (2.59 -> 1.90 ms per 10 000 patterns at
+    // P = 838; the Delaunay path measures 2.05 against 1.89 ms with eight: it keeps four)
+    const int nthr = method == 1 ? PB_THREADS_NEAREST : PB_THREADS_DEFAULT;
+    const size_t lds_run = pattern_build_lds_bytes(G, pool->Pcap, nthr) + (size_t)ctx->tune_pattern_extra_lds;
     const int sp = prof_open(ctx, st, CHEST_K_PLAN);
     if (method == 2) {
-        CHEST_LDS_OPT_IN(ctx, LDS_DELAUNAY_CP, pattern_build_kernel<true>, lds_run);
-        hipLaunchKernelGGL(pattern_build_kernel<true>, dim3((unsigned)count), dim3(PB_THREADS), lds_run, st, a);
+        CHEST_LDS_OPT_IN(ctx, LDS_DELAUNAY_CP, (pattern_build_kernel<true, PB_THREADS_DEFAULT>), lds_run);
+        hipLaunchKernelGGL((pattern_build_kernel<true, PB_THREADS_DEFAULT>), dim3((unsigned)count), dim3(nthr), lds_run, st, a);
+    } else if (method == 1) {
+        CHEST_LDS_OPT_IN(ctx, LDS_DELAUNAY_NEAREST, (pattern_build_kernel<false, PB_THREADS_NEAREST>), lds_run);
+        hipLaunchKernelGGL((pattern_build_kernel<false, PB_THREADS_NEAREST>), dim3((unsigned)count), dim3(nthr), lds_run, st, a);
     } else {
-        CHEST_LDS_OPT_IN(ctx, LDS_DELAUNAY, pattern_build_kernel<false>, lds_run);
-        hipLaunchKernelGGL(pattern_build_kernel<false>, dim3((unsigned)count), dim3(PB_THREADS), lds_run, st, a);
+        CHEST_LDS_OPT_IN(ctx, LDS_DELAUNAY, (pattern_build_kernel<false, PB_THREADS_DEFAULT>), lds_run);
+        hipLaunchKernelGGL((pattern_build_kernel<false, PB_THREADS_DEFAULT>), dim3((unsigned)count), dim3(nthr), lds_run, st, a);
     }
     prof_close(ctx, st, sp);
     CHEST_HIP(hipGetLastError());
