@@ -872,9 +872,7 @@ int launch_k2_slab(chest_ctx* ctx, hipStream_t st, int32_t B, const chest_frame_
         // (4x4 without estimates -- the full-covariance route -- needs 67 KB: two workgroups would fit a CU with a 96-VGPR
         //  instantiation (five waves per SIMD).  Built and measured in round 4: 54 spilled registers, 2.00 against 1.90 ms per
         //  2 304 frames, 4.23 against 4.01 per 4 608 -- the synthesis is bound by the instructions it issues, not by residency;
-        //  profiles/r04_cfg5_frame_kernel_isa.txt.  A second 96-VGPR form that recomputes the tap twiddles per unit instead of
-        //  holding them (24 spills, none in the tap loops) measured 2.28 against 1.93 ms: +18 %, the issue cost of the
-        //  recomputation.  Not kept.)
+        //  profiles/r04_cfg5_frame_kernel_isa.txt.  Not kept.)
         if (!injected && !(fp.half & 1) && T == 4 && R == 4 && RG == 1) return launch_one<896, 4, 4, 4, 1, 1, false>(ctx, LDS_FRAME_640_44, CHEST_SLAB_ARGS);   // (10 compute + up to 4 store waves, <= 128 VGPRs)
         return launch_one<768, 3, 0, 0, 0, 1, true>(ctx, LDS_FRAME_640, CHEST_SLAB_ARGS);
     }
