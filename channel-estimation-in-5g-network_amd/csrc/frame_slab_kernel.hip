@@ -84,6 +84,8 @@ __device__ unsigned long long* g_stamp_buf = nullptr;       // [B][16 waves][16 
 #define STAMP_ADD(i) do { } while (0)
 #endif
 
+typedef float f16v_t __attribute__((ext_vector_type(16)));
+
 struct SlabArgs {
     const FrameParams* fp;
     const PatternDev* pat;
@@ -121,7 +123,13 @@ __host__ __device__ inline int slab_elems(int T, int RG, int nsc, int SS, bool w
 // barriers of a unit sit back to back behind the long compute stretch.  0 = run-time values: full twiddle registers,
 // rows written to the slab as they are produced.
 // CP: the patterns carry compact plans (triangle records + per-element triangle ids, chest_device.h: plan_rec).
-template <int NT, int TT, int RR, int RGT, int SS, bool INJ, bool CP>
+// MF (4x4, one rx antenna and one symbol per unit, device RNG): the tap sum H[r][t][k] = sum_d c_d[r][t] w_d(k) of a symbol -- a complex
+// (16 x NT) x (NT x subcarriers) product -- runs on the MATRIX pipe as v_mfma_f32_32x32x2_f32 (full fp32, same peak as the packed vector
+// FMAs it replaces, but a pipe of its own: the vector ALU keeps the Philox / Box-Muller / symbol work).  Rows of a tile are (rx, re | im, tx),
+// columns 32 subcarriers, one K step per tap (its real and imaginary twiddle row); four tiles -- even / odd subcarriers of the wave's
+// lower / upper 32 pairs -- and a v_permlane32_swap per result register bring every lane the complex values of its own pair for all
+// sixteen antenna pairs.  Computed once per symbol (first rx unit), consumed by the symbol's four units from registers.
+template <int NT, int TT, int RR, int RGT, int SS, bool INJ, bool CP, bool MF = false>
 __device__ __forceinline__ void slab_body(const SlabArgs& A) {
     const FrameParams& fp = *A.fp;
     const PatternDev& pat = *A.pat;
@@ -182,8 +190,26 @@ __device__ __forceinline__ void slab_body(const SlabArgs& A) {
 
     // ---- tap twiddles exp(-2 pi j kappa_k d / N) of this thread's subcarriers: registers for the whole frame ---------
     constexpr int NW = STAGED ? 1 : 2;                           // STAGED keeps the even subcarrier's only
-    float2 w[NT][NW];
-    {
+    static_assert(!MF || (STAGED && TT == 4 && RR == 4 && RGT == 1 && SS == 1 && !INJ), "MF: 4x4, one rx antenna and one symbol per unit");
+    float2 w[MF ? 1 : NT][NW];
+    const float invN_tw = 1.0f / (float)fp.N;
+    auto bin_of = [&](int kc) -> int { return (kc < fp.half) ? (kc - fp.half) : (kc - fp.half + 1); };   // signed bin of a used subcarrier (DC removed)
+    // MF: B operands of the even-subcarrier tiles, [tap][lower | upper 32 pairs of the wave]: lanes 0-31 hold Re w, lanes 32-63 Im w of
+    // subcarrier 2 (wave pair base + (lane & 31) + 32 x)
+    float bq[MF ? NT : 1][2];
+    if constexpr (MF) {
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {
+            const int kx = min(2 * (wave * ppw + (lane & 31) + 32 * x), nsc - 1);
+            const int kax = bin_of(kx);
+#pragma unroll
+            for (int d = 0; d < NT; ++d) {
+                const float2 e = cis_turns((float)(kax * A.prof->delay[d]) * invN_tw);
+                bq[d][x] = lane < 32 ? e.x : -e.y;               // w = conj(exp(2 pi j kappa d / N))
+            }
+        }
+    }
+    if constexpr (!MF) {
         const float invN = 1.0f / (float)fp.N;
         const int half = fp.half;
         const int ka = (kc0 < half) ? (kc0 - half) : (kc0 - half + 1), kb = (kc1 < half) ? (kc1 - half) : (kc1 - half + 1);
@@ -195,12 +221,16 @@ __device__ __forceinline__ void slab_body(const SlabArgs& A) {
             if constexpr (!STAGED) { const float2 e1 = cis_turns((float)(kb * dl) * invN); w[d][NW - 1] = make_float2(e1.x, -e1.y); }
         }
     }
+    auto w_even = [&](int d) -> float2 {                         // twiddle of the pair's even subcarrier
+        if constexpr (MF) { const float2 e = cis_turns((float)(bin_of(kc0) * A.prof->delay[d]) * invN_tw); return make_float2(e.x, -e.y); }   // (estimate phase only)
+        else return w[d][0];
+    };
     auto w_odd = [&](int d) -> float2 {                          // twiddle of the pair's odd subcarrier
         if constexpr (STAGED) {
-            float2 we = w[d][0];
+            float2 we = w_even(d);
             asm volatile("" : "+v"(we.x), "+v"(we.y));           // keeps the product inside the loop: hoisted, it would cost the
             return cmul(we, make_float2(A.prof->step[d][0], A.prof->step[d][1]));   // 2*NT registers this form exists to save
-        } else return w[d][NW - 1];
+        } else return w[MF ? 0 : d][NW - 1];
     };
 
     // SSN consecutive symbols form one unit (STAGED instantiations with RG == R only: a unit's spans stay contiguous across
@@ -247,6 +277,48 @@ __device__ __forceinline__ void slab_body(const SlabArgs& A) {
             sln[ss][0] = slots[sy * nsc + kc0]; sln[ss][1] = slots[sy * nsc + kc1];
         }
     }
+    f16v_t hacc[MF ? 4 : 1];                                      // MF: a symbol's H, all antenna pairs, this lane's subcarrier pair
+    auto mf_burst = [&](int s) {
+        if constexpr (MF) {
+            // A operand of tap d: lane (m = lane & 31, k = lane >> 5) holds A[m][k], row m = (rx = m >> 3, part = (m >> 2) & 1, tx = m & 3):
+            // part re: (Re c, -Im c), part im: (Im c, Re c) against the twiddle rows (Re w, Im w)
+            const int m = lane & 31, kk = lane >> 5, part = (m >> 2) & 1;
+            const float* __restrict__ ca = (const float*)(A.c_g + (size_t)s * KTS * R * T) + (((m >> 3) * T + (m & 3)) * 2 + (part ^ kk));
+            const uint32_t negm = (part == 0 && kk == 1) ? 0x80000000u : 0u;
+            float av[NT];
+#pragma unroll
+            for (int d = 0; d < NT; ++d) av[d] = __uint_as_float(__float_as_uint(ca[d * R * T * 2]) ^ negm);
+#pragma unroll
+            for (int d = 0; d < NT; ++d) {
+                const float sr = A.prof->step[d][0], si = A.prof->step[d][1];
+#pragma unroll
+                for (int x = 0; x < 2; ++x) {
+                    const float own = bq[d][x];
+                    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(own), __float_as_uint(own), false, false);
+                    const float other = __uint_as_float(lane < 32 ? sw[1] : sw[0]);     // the same subcarrier's other part
+                    const float odd = fmaf(own, sr, other * (lane < 32 ? -si : si));     // (w step): Re on lanes 0-31, Im on 32-63
+                    if (d == 0) {
+                        const f16v_t zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                        hacc[x] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[d], own, zero, 0, 0, 0);
+                        hacc[2 + x] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[d], odd, zero, 0, 0, 0);
+                    } else {
+                        hacc[x] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[d], own, hacc[x], 0, 0, 0);
+                        hacc[2 + x] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[d], odd, hacc[2 + x], 0, 0, 0);
+                    }
+                }
+            }
+            // result register v of a tile: row (rx = v >> 2, part = lane >> 5, tx = v & 3), column lane & 31.  Swap the upper half of the
+            // lower-pairs tile with the lower half of the upper-pairs tile: every lane then holds Re (first of the two tiles) and Im
+            // (second) of ITS pair's subcarrier
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const auto e = __builtin_amdgcn_permlane32_swap(__float_as_uint(hacc[0][v]), __float_as_uint(hacc[1][v]), false, false);
+                hacc[0][v] = __uint_as_float(e[0]); hacc[1][v] = __uint_as_float(e[1]);
+                const auto o = __builtin_amdgcn_permlane32_swap(__float_as_uint(hacc[2][v]), __float_as_uint(hacc[3][v]), false, false);
+                hacc[2][v] = __uint_as_float(o[0]); hacc[3][v] = __uint_as_float(o[1]);
+            }
+        }
+    };
     for (int sb = 0; sb < S; sb += SSN) {
         const int ns = SSN == 1 ? 1 : min(SSN, S - sb);                          // symbols of this unit (ragged last unit)
         unsigned sc[SSN][2];
@@ -297,11 +369,26 @@ __device__ __forceinline__ void slab_body(const SlabArgs& A) {
                     if (ss >= ns) continue;
                     const int s = sb + ss;
                     const float2* __restrict__ cs = A.c_g + (size_t)s * KTS * R * T;   // this symbol's gains [tap][r][t]
+                    if constexpr (MF) {
+                        if (rg == 0) mf_burst(s);                                 // the symbol's H for all four rx antennas, into registers
+#define CHEST_MF_ROW(RX)                                                                                                           \
+                        _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                                             \
+                            hv[ss][t][0] = make_float2(hacc[0][4 * (RX) + t], hacc[1][4 * (RX) + t]);                               \
+                            hv[ss][t][1] = make_float2(hacc[2][4 * (RX) + t], hacc[3][4 * (RX) + t]);                               \
+                        }
+                        switch (r0) {                                             // (uniform; static register indices in every arm)
+                            case 0: CHEST_MF_ROW(0) break;
+                            case 1: CHEST_MF_ROW(1) break;
+                            case 2: CHEST_MF_ROW(2) break;
+                            default: CHEST_MF_ROW(3) break;
+                        }
+#undef CHEST_MF_ROW
+                    }
 #pragma unroll
-                    for (int i = 0; i < RGT * TT; ++i) hv[ss][i][0] = hv[ss][i][1] = make_float2(0.f, 0.f);
+                    for (int i = 0; i < RGT * TT; ++i) { if constexpr (!MF) hv[ss][i][0] = hv[ss][i][1] = make_float2(0.f, 0.f); }
 #pragma unroll
-                    for (int d = 0; d < NT; ++d) {
-                        const float2 wa = w[d][0], wb = w_odd(d);
+                    for (int d = 0; d < (MF ? 0 : NT); ++d) {
+                        const float2 wa = w[MF ? 0 : d][0], wb = w_odd(d);
                         const float2* __restrict__ cd = cs + (d * R + r0) * T;   // [rr][t] contiguous: one scalar load per tap
 #pragma unroll
                         for (int i = 0; i < RGT * TT; ++i) {
@@ -573,7 +660,7 @@ __device__ __forceinline__ void slab_body(const SlabArgs& A) {
 #pragma unroll
                         for (int d = 0; d < NT; ++d) {
                             const float2 c = coef[d * R];
-                            cfma(hb0, c, w[d][0]);
+                            cfma(hb0, c, w_even(d));
                             cfma(hb1, c, w_odd(d));
                         }
                         if (act) {
@@ -654,7 +741,7 @@ __device__ __forceinline__ void slab_body(const SlabArgs& A) {
 
 // MAXTHR: largest workgroup this instantiation is launched with (448 = 5 compute waves for nsc <= 640, the 1024-FFT grids, and up
 // to two store waves; 768 = 10 + 2 for the 2048-FFT grids).
-template <int MAXTHR, int MINW, int TT, int RR, int RGT, int SS, bool INJ, bool CP>
+template <int MAXTHR, int MINW, int TT, int RR, int RGT, int SS, bool INJ, bool CP, bool MF = false>
 __global__ void __launch_bounds__(MAXTHR, MINW)
 frame_slab_kernel(const FrameParams* __restrict__ fpp, const chest_frame_desc* __restrict__ descs,
                   const PatternDev* __restrict__ patterns, int Pmax, uint64_t seed, uint64_t frame_offset,
@@ -758,9 +845,9 @@ frame_slab_kernel(const FrameParams* __restrict__ fpp, const chest_frame_desc* _
     // a second slab behind the first when the launch was given the LDS for it (bit 24 of the crew argument) and produces no estimates
     A.slab2 = ((RG >> 24) & 1) && !want_est ? (slab_elems(T, RG & 0xFF, fp.nsc, SS, false) + 1) & ~1 : 0;
     switch (A.prof->ntaps) {                                     // workgroup-uniform dispatch on the profile
-        case 5: slab_body<5, TT, RR, RGT, SS, INJ, CP>(A); break;         // EPA at 15.36 MHz
-        case 8: slab_body<8, TT, RR, RGT, SS, INJ, CP>(A); break;         // EVA
-        default: slab_body<KT, TT, RR, RGT, SS, INJ, CP>(A); break;       // ETU / anything else (taps padded with zeros)
+        case 5: slab_body<5, TT, RR, RGT, SS, INJ, CP, MF>(A); break;     // EPA at 15.36 MHz
+        case 8: slab_body<8, TT, RR, RGT, SS, INJ, CP, MF>(A); break;     // EVA
+        default: slab_body<KT, TT, RR, RGT, SS, INJ, CP, MF>(A); break;   // ETU / anything else (taps padded with zeros)
     }
 #ifdef CHEST_STAMPS
     if (g_stamp_buf != nullptr && (tid & 63) == 0) {
@@ -797,12 +884,12 @@ static int choose_rx_group(const chest_ctx* ctx, int Pmax) {
     return best2 ? best2 : best1;
 }
 
-template <int MAXTHR, int MINW, int TT, int RR, int RGT, int SS, bool INJ, bool CP = false>
+template <int MAXTHR, int MINW, int TT, int RR, int RGT, int SS, bool INJ, bool CP = false, bool MF = false>
 static int launch_one(chest_ctx* ctx, int which, hipStream_t st, dim3 grid, dim3 block, size_t lds, const chest_frame_desc* descs, int Pmax,
                       uint64_t seed, uint64_t frame_offset, const chest_injected& inj, const chest_frame_outputs& out,
                       const float* workspace, int RG) {
-    CHEST_LDS_OPT_IN(ctx, which, (frame_slab_kernel<MAXTHR, MINW, TT, RR, RGT, SS, INJ, CP>), lds);
-    hipLaunchKernelGGL((frame_slab_kernel<MAXTHR, MINW, TT, RR, RGT, SS, INJ, CP>), grid, block, lds, st, ctx->d_fp, descs, ctx->d_patterns, Pmax,
+    CHEST_LDS_OPT_IN(ctx, which, (frame_slab_kernel<MAXTHR, MINW, TT, RR, RGT, SS, INJ, CP, MF>), lds);
+    hipLaunchKernelGGL((frame_slab_kernel<MAXTHR, MINW, TT, RR, RGT, SS, INJ, CP, MF>), grid, block, lds, st, ctx->d_fp, descs, ctx->d_patterns, Pmax,
                        seed, frame_offset, inj, out, workspace, RG, ctx->d_status);
     return CHEST_OK;
 }
@@ -873,6 +960,11 @@ int launch_k2_slab(chest_ctx* ctx, hipStream_t st, int32_t B, const chest_frame_
         //  instantiation (five waves per SIMD).  Built and measured in round 4: 54 spilled registers, 2.00 against 1.90 ms per
         //  2 304 frames, 4.23 against 4.01 per 4 608 -- the synthesis is bound by the instructions it issues, not by residency;
         //  profiles/r04_cfg5_frame_kernel_isa.txt.  Not kept.)
+        // the launch of the full-covariance route (two slabs, 10 + 2 waves): tap sums on the matrix pipe (slab_body, MF): 1.81 against
+        // 1.90 ms per 2 304 frames, 3.70 against 4.09 per 4 608 (tools/ab_mfma_synth.py; chest_tune "frame_min_waves" 4 = the vector-ALU
+        // instantiation, for A/B).  H and rx agree with the vector-ALU form to 2.5e-7 of the tensor's scale (summation order).
+        if (!injected && !(fp.half & 1) && T == 4 && R == 4 && RG == 1 && two_slabs && nwave + nsx <= 12 && ctx->tune_min_waves != 4)
+            return launch_one<768, 3, 4, 4, 1, 1, false, false, true>(ctx, LDS_FRAME_640_44_MF, CHEST_SLAB_ARGS);
         if (!injected && !(fp.half & 1) && T == 4 && R == 4 && RG == 1) return launch_one<896, 4, 4, 4, 1, 1, false>(ctx, LDS_FRAME_640_44, CHEST_SLAB_ARGS);   // (10 compute + up to 4 store waves, <= 128 VGPRs)
         return launch_one<768, 3, 0, 0, 0, 1, true>(ctx, LDS_FRAME_640, CHEST_SLAB_ARGS);
     }

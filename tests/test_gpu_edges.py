@@ -393,3 +393,39 @@ def test_packed_filter_equals_per_call_packing():
     with pytest.raises(ValueError):
         eng.mmse_full_apply_pilots(hls, slot, eng.mmse_full_pack_filter(W[:50, :50].contiguous()))
     eng.close()
+
+
+@pytest.mark.parametrize("ctype", ["EPA", "EVA", "ETU"])
+def test_matrix_pipe_tap_sums_of_the_2048_fft_4x4_launch(ctype):
+    """The launch of the full-covariance route (2048-FFT 4x4, no estimates) computes the tap sums H = sum_d c_d w_d on the matrix pipe
+    (frame_slab_kernel, MF).  Checked against the oracle (same tolerance as every other frame test) and against the vector-ALU
+    instantiation of the same launch (chest_tune "frame_min_waves" 4): symbols, mask and pilot symbols bit for bit, H / rx / pilot LS
+    values to float32 summation order."""
+    geom = E.Geometry(fft_size=2048, cp_length=144, useful_subcarriers=1200, num_tx=4, num_rx=4)
+    eng = E.Engine(geom, 0)
+    S, nsc, T, R = geom.num_symbols, geom.num_sc, 4, 4
+    pil = np.sort(np.random.RandomState(9).permutation(S * nsc)[: (S * nsc) // 10])
+    slot = eng.pattern_slot(pil, "linear")
+    names = ("tx", "rx", "H", "pilot_symbols", "pilot_mask", "h_ls_pilots")
+    B, seed, off = 3, 21, 5
+    d = E.make_descs(ctype, 555.6, 10.0, slot, n=B)
+    try:
+        eng.tune("frame_min_waves", 4)
+        ref = {k: v.clone() for k, v in eng.run_frames(d, seed=seed, frame_offset=off, outputs=names).items() if k in names}
+        eng.tune("frame_min_waves", 0)
+        out = eng.run_frames(d, seed=seed, frame_offset=off, outputs=names)
+    finally:
+        eng.tune("frame_min_waves", 0)
+    for k in ("tx", "pilot_symbols", "pilot_mask"):
+        assert torch.equal(ref[k], out[k]), k
+    for k in ("H", "rx", "h_ls_pilots"):
+        assert float((ref[k] - out[k]).abs().max()) <= 1e-6 * float(ref[k].abs().max()), k
+    ofdm = dict(fft_size=2048, cp_length=144, num_symbols=S, useful_subcarriers=1200, subcarrier_spacing=geom.subcarrier_spacing)
+    L = len(O.PROFILES[ctype][0])
+    for b in range(B):
+        dr = PH.native_frame_draws(seed, off + b, pil, S, nsc, T, R, L)
+        o = O.simulate_frame(ofdm, dict(num_tx=T, num_rx=R), ctype, 555.6, 10.0, dr)
+        assert relerr(out["H"][b].cpu().numpy(), o["channel"]) < TOL
+        assert relerr(out["rx"][b].cpu().numpy(), o["rx_symbols"]) < TOL
+        assert relerr(out["tx"][b].cpu().numpy(), o["tx_symbols"]) < TOL
+    eng.close()

@@ -10,6 +10,7 @@ names = ("tx", "rx", "H", "pilot_symbols", "pilot_mask", "h_ls_pilots")
 geom = E.Geometry(fft_size=2048, cp_length=144, useful_subcarriers=1200, num_tx=4, num_rx=4)
 F = int(sys.argv[1]) if len(sys.argv) > 1 else 2304
 eng = E.Engine(geom, 0)
+eng.tune("frame_min_waves", 4)          # the vector-ALU instantiation in both arms (the two-slab default runs its tap sums on the matrix pipe)
 slots = eng.build_patterns(0, [geom.grid // 10], seed=1, pattern_ids=np.arange(1, dtype=np.uint64), method="linear")
 d = torch.from_numpy(E.make_descs("ETU", 555.6, 10.0, int(slots[0]), n=F).view(np.uint8).copy()).to(eng.device)
 eng.tune("frame_two_slabs", -1)

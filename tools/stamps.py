@@ -24,7 +24,9 @@ def main():
     N = importlib.import_module(PKG + "._native")
     F = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
     cfg5 = os.environ.get("STAMPS_SHAPE") == "cfg5"          # the 2048-FFT 4x4 launch of config 5 (no estimates; 10 compute waves + store waves)
-    geom = E.Geometry(fft_size=2048, cp_length=144, useful_subcarriers=1200, num_tx=4, num_rx=4) if cfg5 else E.Geometry()
+    siso = os.environ.get("STAMPS_SHAPE") == "siso"          # config 1's shape: 1x1, EPA, 5.56 Hz (two symbols per unit)
+    geom = E.Geometry(fft_size=2048, cp_length=144, useful_subcarriers=1200, num_tx=4, num_rx=4) if cfg5 else \
+        (E.Geometry(num_tx=1, num_rx=1) if siso else E.Geometry())
     eng = E.Engine(geom, 0)
     if os.environ.get("STAMPS_ONE_SLAB"):
         eng.tune("frame_two_slabs", -1)
@@ -33,14 +35,14 @@ def main():
     P = int(G * 0.1)
     per_frame = len(sys.argv) > 3 and sys.argv[3] == "pf"           # one device-built pattern (and plan) per frame
     if per_frame:
-        sl = eng.build_patterns(0, np.full(F, P, np.int32), seed=2024, pattern_ids=np.arange(F, dtype=np.uint64), method="linear")
+        sl = eng.build_patterns(0, np.full(F, P, np.int32), seed=2024, pattern_ids=np.arange(F, dtype=np.uint64), method=os.environ.get("STAMPS_PLAN", "linear_compact"))
         descs = E.make_descs("EVA", 111.1, 10.0, np.asarray(sl, np.int32), n=F)
     else:
         slots = []
         for g in range((F + 1023) // 1024):
             perm = np.arange(G); np.random.RandomState(2024 + g).shuffle(perm)
             slots.append(eng.pattern_slot(np.sort(perm[:P]), "linear"))
-        descs = E.make_descs("ETU" if cfg5 else "EVA", 555.6 if cfg5 else 111.1, 10.0, np.asarray(slots, np.int32)[np.arange(F) // 1024], n=F)
+        descs = E.make_descs("ETU" if cfg5 else ("EPA" if siso else "EVA"), 555.6 if cfg5 else (5.56 if siso else 111.1), 10.0, np.asarray(slots, np.int32)[np.arange(F) // 1024], n=F)
     d_dev = torch.from_numpy(descs.view(np.uint8).copy()).to(eng.device)
     names = ["tx", "rx", "H", "pilot_symbols", "pilot_mask", "h_ls_pilots"] if cfg5 else ["tx", "rx", "H", "H_ls", "H_mmse", "pilot_symbols", "pilot_mask"]
     out = eng.run_frames(d_dev, seed=1, outputs=names)
