@@ -646,6 +646,13 @@ __device__ __forceinline__ void slab_body(const SlabArgs& A) {
             if (want_metrics && cw) {
                 // sum_t |H_t - v|^2 = sum_t |H_t - Hbar|^2 + T |Hbar - v|^2 ; the first term is
                 // estimate-independent and comes analytically from K1 (ST_SUM_VAR).
+                // (STAGED: the tap twiddles are RECOMPUTED here, once per unit, instead of staying in 2 NT registers through the whole
+                //  estimate phase, which was the kernel's register peak)
+                float2 we_m[STAGED && !MF ? NT : 1];
+                if constexpr (STAGED && !MF) {
+#pragma unroll
+                    for (int d = 0; d < NT; ++d) { const float2 e = cis_turns((float)(bin_of(kc0) * A.prof->delay[d]) * invN_tw); we_m[d] = make_float2(e.x, -e.y); }
+                }
 #pragma unroll
                 for (int ss = 0; ss < SSN; ++ss) {
                     if (ss >= ns) continue;
@@ -660,8 +667,13 @@ __device__ __forceinline__ void slab_body(const SlabArgs& A) {
 #pragma unroll
                         for (int d = 0; d < NT; ++d) {
                             const float2 c = coef[d * R];
-                            cfma(hb0, c, w_even(d));
-                            cfma(hb1, c, w_odd(d));
+                            if constexpr (STAGED && !MF) {
+                                cfma(hb0, c, we_m[d]);
+                                cfma(hb1, c, cmul(we_m[d], make_float2(A.prof->step[d][0], A.prof->step[d][1])));
+                            } else {
+                                cfma(hb0, c, w_even(d));
+                                cfma(hb1, c, w_odd(d));
+                            }
                         }
                         if (act) {
                             const float2 m = make_float2(hb0.x * invT, hb0.y * invT), f = make_float2(al * e0.x, al * e0.y);
@@ -931,27 +943,38 @@ int launch_k2_slab(chest_ctx* ctx, hipStream_t st, int32_t B, const chest_frame_
     const int RGarg = RG | (ctx->tune_store_waves << 8) | (nsx << 16) | ((two_slabs ? 1 : 0) << 24);   // (crew parameters ride in the high bits of the kernel argument)
     const dim3 grid((unsigned)B), block((unsigned)(nwave + nsx) * 64);
 #define CHEST_SLAB_ARGS st, grid, block, lds, descs, Pmax, seed, frame_offset, inj, out, workspace, RGarg
+    const bool w5 = ctx->tune_min_waves == 5;                 // (A/B) the 96-VGPR instantiations of the 5-wave workgroups
     if (compact) {
         // compact plans (chest_patterns_build method 2; every frame of the launch must use one -- the kernel flags a frame whose
         // pattern is in the other format): the device-RNG instantiations of the 1024-FFT grids and the generic one
         if (nwave > 5) { set_error("compact interpolation plans are read by the frame kernels of grids up to 640 used subcarriers (got %d)", fp.nsc); return CHEST_EINVAL; }
         if (!injected && !(fp.half & 1)) {
-            if (T == 2 && R == 2 && RG == 2) return launch_one<448, 5, 2, 2, 2, 1, false, true>(ctx, LDS_FRAME_CP, CHEST_SLAB_ARGS);
+            // (80-VGPR instantiations for the 5-wave workgroups: see the note on workgroup placement below)
+            if (T == 2 && R == 2 && RG == 2 && w5) return launch_one<448, 5, 2, 2, 2, 1, false, true>(ctx, LDS_FRAME_CP_W5, CHEST_SLAB_ARGS);
+            if (T == 2 && R == 2 && RG == 2) return launch_one<448, 6, 2, 2, 2, 1, false, true>(ctx, LDS_FRAME_CP, CHEST_SLAB_ARGS);
             if (T == 4 && R == 4 && RG == 1) return launch_one<448, 4, 4, 4, 1, 1, false, true>(ctx, LDS_FRAME_44_CP, CHEST_SLAB_ARGS);
-            if (siso) return launch_one<448, 5, 1, 1, 1, SS_SISO, false, true>(ctx, LDS_FRAME_11_CP, CHEST_SLAB_ARGS);
+            if (siso && w5) return launch_one<448, 5, 1, 1, 1, SS_SISO, false, true>(ctx, LDS_FRAME_11_CP_W5, CHEST_SLAB_ARGS);
+            if (siso) return launch_one<448, 6, 1, 1, 1, SS_SISO, false, true>(ctx, LDS_FRAME_11_CP, CHEST_SLAB_ARGS);
         }
         return launch_one<448, 4, 0, 0, 0, 1, true, true>(ctx, LDS_FRAME_GEN_CP, CHEST_SLAB_ARGS);
     }
     if (nwave <= 5) {                      // the 1024-FFT grids (nsc <= 640): specialised antenna counts on the device-RNG path
         if (!injected) {
             if (fp.half & 1) return launch_one<448, 4, 0, 0, 0, 1, true>(ctx, LDS_FRAME_GEN, CHEST_SLAB_ARGS);   // a pair straddles DC
-            // 2x2: 96 VGPRs (five waves per SIMD) so that THREE 5-wave workgroups are resident per CU -- at 128 VGPRs only two
-            // are placed although 15 waves would fit; 2.00 against 2.33 ms per 10 000 frames (chest_tune "frame_min_waves" = 4
-            // selects the 128-VGPR instantiation for A/B)
+            // Workgroup placement (round 4, tools/micro/dispatch_rate.hip, profiles/r04_workgroup_placement.txt).  Three 5-wave workgroups
+            // per CU are 15 waves; at 96 VGPRs a SIMD has room for five, 20 per CU -- and the dispatcher still leaves a freed slot empty
+            // for 35 us on average (a 5-wave workgroup needs TWO wave slots on one SIMD; whether the SIMD its placement starts on has
+            // them is luck): 2.38 workgroups resident on average, not 3.  A kernel that only waits shows the same: 2.25-2.44 resident at
+            // 96 VGPRs, 2.64 at 80 (six waves per SIMD), 2.74 at 64 or with 4-wave workgroups.  So the 5-wave instantiations are built
+            // for 80 VGPRs: 2.86 resident, refill gap 1 us, 1.81 against 1.96 ms per 10 000 2x2 EVA frames.  (Getting there took the
+            // tap twiddles out of the estimate phase -- recomputed once per unit there, 96 -> 89 VGPRs -- the rest is 20 spilled
+            // registers.)  chest_tune "frame_min_waves" 5 / 4 select the 96- / 128-VGPR instantiations for A/B.
             if (T == 2 && R == 2 && RG == 2 && ctx->tune_min_waves == 4) return launch_one<448, 4, 2, 2, 2, 1, false>(ctx, LDS_FRAME_W5, CHEST_SLAB_ARGS);
-            if (T == 2 && R == 2 && RG == 2) return launch_one<448, 5, 2, 2, 2, 1, false>(ctx, LDS_FRAME, CHEST_SLAB_ARGS);
+            if (T == 2 && R == 2 && RG == 2 && w5) return launch_one<448, 5, 2, 2, 2, 1, false>(ctx, LDS_FRAME_W6, CHEST_SLAB_ARGS);
+            if (T == 2 && R == 2 && RG == 2) return launch_one<448, 6, 2, 2, 2, 1, false>(ctx, LDS_FRAME, CHEST_SLAB_ARGS);
             if (T == 4 && R == 4 && RG == 1) return launch_one<448, 4, 4, 4, 1, 1, false>(ctx, LDS_FRAME_44, CHEST_SLAB_ARGS);
-            if (siso) return launch_one<448, 5, 1, 1, 1, SS_SISO, false>(ctx, LDS_FRAME_11, CHEST_SLAB_ARGS);
+            if (siso && w5) return launch_one<448, 5, 1, 1, 1, SS_SISO, false>(ctx, LDS_FRAME_11_W5, CHEST_SLAB_ARGS);
+            if (siso) return launch_one<448, 6, 1, 1, 1, SS_SISO, false>(ctx, LDS_FRAME_11, CHEST_SLAB_ARGS);
         }
         return launch_one<448, 4, 0, 0, 0, 1, true>(ctx, LDS_FRAME_GEN, CHEST_SLAB_ARGS);
     }

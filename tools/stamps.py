@@ -74,6 +74,24 @@ def main():
             cur += d; peak = max(peak, cur)
         conc.append((m.sum(), peak, area / max(ev[-1][0] - ev[0][0], 1)))
     conc = np.asarray(conc)
+    # how long a freed slot stays empty: the k-th workgroup start on a CU (beyond the first `peak`) against the (k - peak)-th end
+    gaps = []
+    for key in np.unique(cu_key):
+        m = cu_key == key
+        st_, en_ = np.sort(rt0[m]), np.sort(rt1[m])
+        pk = int(conc[list(np.unique(cu_key)).index(key), 1])
+        if len(st_) > pk:
+            gaps.extend(((st_[pk:] - en_[: len(st_) - pk]) / 100.0).tolist())
+    gaps = np.asarray(gaps)
+    if os.environ.get("STAMPS_TIMELINE"):                     # the workgroups of the first CUs, in start order: frame, start, end (us since the launch's first start)
+        t0 = rt0.min()
+        for key in np.unique(cu_key)[: int(os.environ["STAMPS_TIMELINE"])]:
+            idx = np.nonzero(cu_key == key)[0]
+            idx = idx[np.argsort(rt0[idx])]
+            print(f"CU {key:#x}: " + "  ".join(f"{i}:{(rt0[i] - t0) / 100:.0f}-{(rt1[i] - t0) / 100:.0f}" for i in idx))
+    if len(gaps):
+        print(f"slot refill gap (end of a workgroup -> start of the next one on that CU): median {np.median(gaps):.1f} us, p10 {np.percentile(gaps, 10):.1f}, "
+              f"p90 {np.percentile(gaps, 90):.1f}, mean {gaps.mean():.1f} us  ({len(gaps)} refills)")
     print(f"CUs seen {len(conc)}; frames per CU {conc[:, 0].min():.0f}..{conc[:, 0].max():.0f}; peak resident workgroups per CU "
           f"{conc[:, 1].min():.0f}..{conc[:, 1].max():.0f}; time-averaged {conc[:, 2].mean():.2f}")
     nw = 14 if cfg5 else 5
