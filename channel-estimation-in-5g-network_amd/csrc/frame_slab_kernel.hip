@@ -384,10 +384,14 @@ __device__ __forceinline__ void slab_body(const SlabArgs& A) {
                         }
 #undef CHEST_MF_ROW
                     }
+                    // the first tap of every profile sits at delay 0 (the launcher checks): its twiddle is 1, the accumulators start from its gains
+                    if constexpr (!MF) {
+                        const float2* __restrict__ cd = cs + r0 * T;
 #pragma unroll
-                    for (int i = 0; i < RGT * TT; ++i) { if constexpr (!MF) hv[ss][i][0] = hv[ss][i][1] = make_float2(0.f, 0.f); }
+                        for (int i = 0; i < RGT * TT; ++i) hv[ss][i][0] = hv[ss][i][1] = cd[i];
+                    }
 #pragma unroll
-                    for (int d = 0; d < (MF ? 0 : NT); ++d) {
+                    for (int d = 1; d < (MF ? 0 : NT); ++d) {
                         const float2 wa = w[MF ? 0 : d][0], wb = w_odd(d);
                         const float2* __restrict__ cd = cs + (d * R + r0) * T;   // [rr][t] contiguous: one scalar load per tap
 #pragma unroll
@@ -651,7 +655,8 @@ __device__ __forceinline__ void slab_body(const SlabArgs& A) {
                 float2 we_m[STAGED && !MF ? NT : 1];
                 if constexpr (STAGED && !MF) {
 #pragma unroll
-                    for (int d = 0; d < NT; ++d) { const float2 e = cis_turns((float)(bin_of(kc0) * A.prof->delay[d]) * invN_tw); we_m[d] = make_float2(e.x, -e.y); }
+                    for (int d = 1; d < NT; ++d) { const float2 e = cis_turns((float)(bin_of(kc0) * A.prof->delay[d]) * invN_tw); we_m[d] = make_float2(e.x, -e.y); }
+                    we_m[0] = make_float2(1.f, 0.f);                       // (delay 0)
                 }
 #pragma unroll
                 for (int ss = 0; ss < SSN; ++ss) {
@@ -921,13 +926,18 @@ int launch_k2_slab(chest_ctx* ctx, hipStream_t st, int32_t B, const chest_frame_
     if (nwave + nsx > 16) nsx = 0;
 
     const int T = fp.T, R = fp.R;
-    const bool injected = inj.u_sym || inj.u_angle || inj.n_re;         // parity / replay mode: the generic instantiations
+    const bool injected_in = inj.u_sym || inj.u_angle || inj.n_re;      // parity / replay mode: the generic instantiations
     // SISO frames have three rows per symbol: two symbols per unit halve the per-unit synchronisation (the spans of
     // consecutive symbols are contiguous when a unit holds all rx antennas)
 #ifndef CHEST_SS_SISO
 #define CHEST_SS_SISO 2
 #endif
     constexpr int SS_SISO = CHEST_SS_SISO;
+    // the specialised (device-RNG) instantiations start their tap sums from the first tap's gains: every profile's first tap must sit at
+    // delay 0 (true of the reference's three tables at any sampling rate); otherwise the generic instantiations run
+    bool zero_first = true;
+    for (int ty = 0; ty < CHEST_NUM_PROFILES; ++ty) zero_first = zero_first && fp.prof[ty].ntaps > 0 && fp.prof[ty].delay[0] == 0;
+    const bool injected = injected_in || !zero_first;
     const bool siso = !injected && !(fp.half & 1) && nwave <= 5 && T == 1 && R == 1 && RG == 1;
     // a launch without estimates (H_ls / H_mmse / metrics) keeps neither the pilot table nor the estimate segments in LDS
     const bool want_est = out.H_ls != nullptr || out.H_mmse != nullptr || out.metrics != nullptr;
