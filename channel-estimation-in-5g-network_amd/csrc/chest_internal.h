@@ -84,7 +84,7 @@ struct chest_ctx {
     struct ProfSpan { int32_t id; void* a; void* b; };     // hipEvent_t pair around one kernel (group) of kind `id` (CHEST_K_*)
     std::vector<ProfSpan> prof_spans;     // pool created by chest_profile_begin; launches never allocate
     int32_t prof_used = 0;                // spans recorded since chest_profile_begin / the last chest_profile_read
-    size_t lds_opt_in[31] = {};   // largest dynamic-LDS size already opted in per kernel (per context = per device)
+    size_t lds_opt_in[32] = {};   // largest dynamic-LDS size already opted in per kernel (per context = per device)
     // chest_tune (tools / experiments only; nothing on the launch path reads the environment)
     int32_t tune_rx_group = 0;            // rx antennas per slab unit of the frame kernel (0 = chosen from the LDS budget)
     int32_t tune_taps_threads = 0;        // taps kernel workgroup size 64 / 128 / 256 (0 = by antenna count)
@@ -92,7 +92,7 @@ struct chest_ctx {
     int32_t tune_two_slabs = 0;           // -1: no second slab for the one-workgroup-per-CU frame kernel (A/B)
     int32_t tune_store_extra = 0;         // dedicated store waves per frame workgroup (0 = the default of the launcher, -1 = none); experiments
     int32_t tune_store_waves = 0;         // waves of a frame workgroup that stream the slab out (0 = the rule in slab_body); experiments
-    int32_t tune_min_waves = 0;           // 4 = the 128-VGPR instantiation of the 2x2 frame kernel (two workgroups per CU), for A/B
+    int32_t tune_min_waves = 0;           // A/B of frame-kernel instantiations by register budget: 5 = 96 VGPRs (5-wave workgroups), 4 = 128 (2x2; also the vector-ALU form of the 2048-FFT 4x4 launch), 6 = 80 (SISO)
     int32_t tune_pattern_extra_lds = 0;   // bytes of unused LDS added to the pattern kernel's allocation (occupancy experiments)
     int32_t tune_pattern_solo_at = 0;     // active triangles at which the pattern kernel's flips go to one wave (0 = default 192)
     int32_t tune_pattern_stop_after = 0;  // diagnostic: the pattern kernel leaves after phase k (instruction counts per phase; tools/pmc_pattern_phases.sh)
@@ -113,7 +113,7 @@ void set_error(const char* fmt, ...);
 
 enum { LDS_TAPS = 0, LDS_FRAME = 1, LDS_ESTIMATE = 2, LDS_INTERP = 3, LDS_GEMM = 4, LDS_GEMM3M = 5, LDS_FRAME_640 = 6,
        LDS_FRAME_1024 = 7, LDS_FRAME_ROWS = 8, LDS_DELAUNAY = 9, LDS_FRAME_44 = 10, LDS_FRAME_11 = 11, LDS_FRAME_GEN = 12, LDS_FRAME_W5 = 13, LDS_GJ_PANEL = 14, LDS_GJ_UPDATE = 15, LDS_GJ_PANEL_R = 16, LDS_GJ_UPDATE_R = 17, LDS_FRAME_640_44 = 18, LDS_INTERP_TFOLD = 19,
-       LDS_FRAME_CP = 20, LDS_FRAME_44_CP = 21, LDS_FRAME_11_CP = 22, LDS_FRAME_GEN_CP = 23, LDS_DELAUNAY_CP = 24, LDS_DELAUNAY_NEAREST = 25, LDS_FRAME_640_44_MF = 26, LDS_FRAME_W6 = 27, LDS_FRAME_CP_W5 = 28, LDS_FRAME_11_CP_W5 = 29, LDS_FRAME_11_W5 = 30 };
+       LDS_FRAME_CP = 20, LDS_FRAME_44_CP = 21, LDS_FRAME_11_CP = 22, LDS_FRAME_GEN_CP = 23, LDS_DELAUNAY_CP = 24, LDS_DELAUNAY_NEAREST = 25, LDS_FRAME_640_44_MF = 26, LDS_FRAME_W6 = 27, LDS_FRAME_CP_W5 = 28, LDS_FRAME_11_CP_W5 = 29, LDS_FRAME_11_W5 = 30, LDS_FRAME_11_W7 = 31 };
 
 // RAII: make the context's device current for the duration of an entry point and restore the caller's afterwards
 struct DeviceGuard {

@@ -984,7 +984,10 @@ int launch_k2_slab(chest_ctx* ctx, hipStream_t st, int32_t B, const chest_frame_
             if (T == 2 && R == 2 && RG == 2) return launch_one<448, 6, 2, 2, 2, 1, false>(ctx, LDS_FRAME, CHEST_SLAB_ARGS);
             if (T == 4 && R == 4 && RG == 1) return launch_one<448, 4, 4, 4, 1, 1, false>(ctx, LDS_FRAME_44, CHEST_SLAB_ARGS);
             if (siso && w5) return launch_one<448, 5, 1, 1, 1, SS_SISO, false>(ctx, LDS_FRAME_11_W5, CHEST_SLAB_ARGS);
-            if (siso) return launch_one<448, 6, 1, 1, 1, SS_SISO, false>(ctx, LDS_FRAME_11, CHEST_SLAB_ARGS);
+            // (SISO: 36 KB of LDS, FOUR workgroups fit a CU -- 20 waves: 72 VGPRs, seven wave slots per SIMD, place them best: 0.89 ms per
+            //  10 000 frames at the 96-VGPR budget, 0.77 at 80, 0.73 at 72 (18 spilled registers), 0.76 at 64; "frame_min_waves" 6 = 80)
+            if (siso && ctx->tune_min_waves == 6) return launch_one<448, 6, 1, 1, 1, SS_SISO, false>(ctx, LDS_FRAME_11_W7, CHEST_SLAB_ARGS);
+            if (siso) return launch_one<448, 7, 1, 1, 1, SS_SISO, false>(ctx, LDS_FRAME_11, CHEST_SLAB_ARGS);
         }
         return launch_one<448, 4, 0, 0, 0, 1, true>(ctx, LDS_FRAME_GEN, CHEST_SLAB_ARGS);
     }
