@@ -962,7 +962,7 @@ int launch_k2_slab(chest_ctx* ctx, hipStream_t st, int32_t B, const chest_frame_
             // (80-VGPR instantiations for the 5-wave workgroups: see the note on workgroup placement below)
             if (T == 2 && R == 2 && RG == 2 && w5) return launch_one<448, 5, 2, 2, 2, 1, false, true>(ctx, LDS_FRAME_CP_W5, CHEST_SLAB_ARGS);
             if (T == 2 && R == 2 && RG == 2) return launch_one<448, 6, 2, 2, 2, 1, false, true>(ctx, LDS_FRAME_CP, CHEST_SLAB_ARGS);
-            if (T == 4 && R == 4 && RG == 1) return launch_one<448, 4, 4, 4, 1, 1, false, true>(ctx, LDS_FRAME_44_CP, CHEST_SLAB_ARGS);
+            if (T == 4 && R == 4 && RG == 1) return launch_one<448, 5, 4, 4, 1, 1, false, true>(ctx, LDS_FRAME_44_CP, CHEST_SLAB_ARGS);
             if (siso && w5) return launch_one<448, 5, 1, 1, 1, SS_SISO, false, true>(ctx, LDS_FRAME_11_CP_W5, CHEST_SLAB_ARGS);
             if (siso) return launch_one<448, 6, 1, 1, 1, SS_SISO, false, true>(ctx, LDS_FRAME_11_CP, CHEST_SLAB_ARGS);
         }
@@ -982,7 +982,11 @@ int launch_k2_slab(chest_ctx* ctx, hipStream_t st, int32_t B, const chest_frame_
             if (T == 2 && R == 2 && RG == 2 && ctx->tune_min_waves == 4) return launch_one<448, 4, 2, 2, 2, 1, false>(ctx, LDS_FRAME_W5, CHEST_SLAB_ARGS);
             if (T == 2 && R == 2 && RG == 2 && w5) return launch_one<448, 5, 2, 2, 2, 1, false>(ctx, LDS_FRAME_W6, CHEST_SLAB_ARGS);
             if (T == 2 && R == 2 && RG == 2) return launch_one<448, 6, 2, 2, 2, 1, false>(ctx, LDS_FRAME, CHEST_SLAB_ARGS);
-            if (T == 4 && R == 4 && RG == 1) return launch_one<448, 4, 4, 4, 1, 1, false>(ctx, LDS_FRAME_44, CHEST_SLAB_ARGS);
+            // (4x4: two 7-wave workgroups per CU, 5 compute + 2 store waves.  At the 128-VGPR budget -- four wave slots per SIMD, 16 for 14
+            //  waves -- 1.72 of 2 were resident (refill gap mean 51 us of a 333-us lifetime); at 96 VGPRs 1.93 (gap 7 us): 4.41 -> 4.22 ms per
+            //  6 250 ETU frames; 80 VGPRs spill 62 registers, 4.67.  "frame_min_waves" 4 = the 128-VGPR instantiation)
+            if (T == 4 && R == 4 && RG == 1 && ctx->tune_min_waves == 4) return launch_one<448, 4, 4, 4, 1, 1, false>(ctx, LDS_FRAME_44_W5, CHEST_SLAB_ARGS);
+            if (T == 4 && R == 4 && RG == 1) return launch_one<448, 5, 4, 4, 1, 1, false>(ctx, LDS_FRAME_44, CHEST_SLAB_ARGS);
             if (siso && w5) return launch_one<448, 5, 1, 1, 1, SS_SISO, false>(ctx, LDS_FRAME_11_W5, CHEST_SLAB_ARGS);
             // (SISO: 36 KB of LDS, FOUR workgroups fit a CU -- 20 waves: 72 VGPRs, seven wave slots per SIMD, place them best: 0.89 ms per
             //  10 000 frames at the 96-VGPR budget, 0.77 at 80, 0.73 at 72 (18 spilled registers), 0.76 at 64; "frame_min_waves" 6 = 80)

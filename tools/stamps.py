@@ -25,8 +25,9 @@ def main():
     F = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
     cfg5 = os.environ.get("STAMPS_SHAPE") == "cfg5"          # the 2048-FFT 4x4 launch of config 5 (no estimates; 10 compute waves + store waves)
     siso = os.environ.get("STAMPS_SHAPE") == "siso"          # config 1's shape: 1x1, EPA, 5.56 Hz (two symbols per unit)
+    cfg3 = os.environ.get("STAMPS_SHAPE") == "cfg3"          # config 3's shape: 4x4, 1024-FFT, ETU (5 compute + 2 store waves, two workgroups per CU)
     geom = E.Geometry(fft_size=2048, cp_length=144, useful_subcarriers=1200, num_tx=4, num_rx=4) if cfg5 else \
-        (E.Geometry(num_tx=1, num_rx=1) if siso else E.Geometry())
+        (E.Geometry(num_tx=1, num_rx=1) if siso else (E.Geometry(num_tx=4, num_rx=4) if cfg3 else E.Geometry()))
     eng = E.Engine(geom, 0)
     if os.environ.get("STAMPS_ONE_SLAB"):
         eng.tune("frame_two_slabs", -1)
@@ -42,7 +43,7 @@ def main():
         for g in range((F + 1023) // 1024):
             perm = np.arange(G); np.random.RandomState(2024 + g).shuffle(perm)
             slots.append(eng.pattern_slot(np.sort(perm[:P]), "linear"))
-        descs = E.make_descs("ETU" if cfg5 else ("EPA" if siso else "EVA"), 555.6 if cfg5 else (5.56 if siso else 111.1), 10.0, np.asarray(slots, np.int32)[np.arange(F) // 1024], n=F)
+        descs = E.make_descs("ETU" if (cfg5 or cfg3) else ("EPA" if siso else "EVA"), 555.6 if cfg5 else (370.4 if cfg3 else (5.56 if siso else 111.1)), 10.0, np.asarray(slots, np.int32)[np.arange(F) // 1024], n=F)
     d_dev = torch.from_numpy(descs.view(np.uint8).copy()).to(eng.device)
     names = ["tx", "rx", "H", "pilot_symbols", "pilot_mask", "h_ls_pilots"] if cfg5 else ["tx", "rx", "H", "H_ls", "H_mmse", "pilot_symbols", "pilot_mask"]
     out = eng.run_frames(d_dev, seed=1, outputs=names)
@@ -94,7 +95,7 @@ def main():
               f"p90 {np.percentile(gaps, 90):.1f}, mean {gaps.mean():.1f} us  ({len(gaps)} refills)")
     print(f"CUs seen {len(conc)}; frames per CU {conc[:, 0].min():.0f}..{conc[:, 0].max():.0f}; peak resident workgroups per CU "
           f"{conc[:, 1].min():.0f}..{conc[:, 1].max():.0f}; time-averaged {conc[:, 2].mean():.2f}")
-    nw = 14 if cfg5 else 5
+    nw = 14 if cfg5 else (7 if cfg3 else 5)
     st = raw[:, :nw, :12].astype(np.float64)      # waves per workgroup (compute waves first, then any store waves)
     tot = st.sum(axis=2)
     print(f"stamped kernel {ms:.3f} ms; mean stamped cycles per wave per frame {tot.mean():,.0f}")
