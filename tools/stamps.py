@@ -13,7 +13,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 PKG = "channel-estimation-in-5g-network_amd"
-os.environ["CHEST_LIB"] = os.path.join(ROOT, PKG, "libchest_stamps.so")
+os.environ["CHEST_LIB"] = os.path.join(ROOT, PKG, os.environ.get("STAMPS_LIB", "libchest_stamps.so"))
 NAMES = ["W compute", "W barrier B", "W slab write", "W barrier A", "W store-out", "barrier after W", "pilots+alpha",
          "E compute", "E barrier B", "E slab write", "E barrier A", "E store-out"]
 
