@@ -977,8 +977,9 @@ int launch_k2_slab(chest_ctx* ctx, hipStream_t st, int32_t B, const chest_frame_
             // them is luck): 2.38 workgroups resident on average, not 3.  A kernel that only waits shows the same: 2.25-2.44 resident at
             // 96 VGPRs, 2.64 at 80 (six waves per SIMD), 2.74 at 64 or with 4-wave workgroups.  So the 5-wave instantiations are built
             // for 80 VGPRs: 2.86 resident, refill gap 1 us, 1.81 against 1.96 ms per 10 000 2x2 EVA frames.  (Getting there took the
-            // tap twiddles out of the estimate phase -- recomputed once per unit there, 96 -> 89 VGPRs -- the rest is 20 spilled
-            // registers.)  chest_tune "frame_min_waves" 5 / 4 select the 96- / 128-VGPR instantiations for A/B.
+            // tap twiddles out of the estimate phase -- recomputed once per unit there, 96 -> 89 VGPRs --, starting the tap sums from the
+            // zero-delay first tap's gains, 89 -> 85, and a handful of spilled registers.)  chest_tune "frame_min_waves" 5 / 4 select the
+            // 96- / 128-VGPR instantiations for A/B.
             if (T == 2 && R == 2 && RG == 2 && ctx->tune_min_waves == 4) return launch_one<448, 4, 2, 2, 2, 1, false>(ctx, LDS_FRAME_W5, CHEST_SLAB_ARGS);
             if (T == 2 && R == 2 && RG == 2 && w5) return launch_one<448, 5, 2, 2, 2, 1, false>(ctx, LDS_FRAME_W6, CHEST_SLAB_ARGS);
             if (T == 2 && R == 2 && RG == 2) return launch_one<448, 6, 2, 2, 2, 1, false>(ctx, LDS_FRAME, CHEST_SLAB_ARGS);
