@@ -130,15 +130,52 @@ def _selftest_spawn(world, rank):
 # =====================================================================================================
 # CPU baseline: the oracle in *faithful* mode on this box's host cores
 # =====================================================================================================
-def cpu_baseline(workload, budget_s=20.0):
+def usable_cores():
+    """Host cores this process may actually run on: the scheduler affinity, capped by the container's CPU quota (cgroup v2
+    cpu.max / v1 cfs_quota) when there is one -- on a box that shows 256 cores but grants a 16-CPU quota, 256 processes compute
+    no faster than 16.  Returns (cores, record of what was seen)."""
+    seen = {"os_cpu_count": os.cpu_count()}
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        n = os.cpu_count() or 1
+    seen["affinity"] = n
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(per)
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except Exception:
+            pass
+    seen["cgroup_cpu_quota"] = quota
+    if quota is not None:
+        n = max(1, min(n, int(quota + 0.999)))
+    return n, seen
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return None
+
+
+def cpu_baseline(workload, budget_s=15.0):
     """Time the oracle in *faithful* mode (the reference's algorithmic structure: full-length Jakes synthesis, per-RE
-    channel loop, SciPy griddata per antenna pair, dense PxP inverse) on the host cores of this box.  One process per
-    core, a bounded number of frames each."""
+    channel loop, SciPy griddata per antenna pair, dense PxP inverse) on the host cores of this box: ONE PROCESS PER USABLE
+    CORE, a bounded number of frames each (about `budget_s` seconds of wall time)."""
     import multiprocessing as mp
     w = WORKLOADS[workload]
-    cores = min(os.cpu_count() or 1, 16)
-    if w["kind"] == "fullcov":
-        cores = min(cores, 8)                                   # 16 dense 1678x1678 complex inverses per frame: bound the sample
+    cores, seen = usable_cores()
     t0 = time.time()
     _cpu_frames((workload, 1, 12345))                           # one frame to size the sample
     one = time.time() - t0
@@ -146,7 +183,7 @@ def cpu_baseline(workload, budget_s=20.0):
     ctx = mp.get_context("spawn")
     t0 = time.time()
     with ctx.Pool(cores) as pool:
-        parts = pool.map(_cpu_frames, [(workload, per_proc, 1000 + i) for i in range(cores)])
+        parts = pool.map(_cpu_frames, [(workload, per_proc, 1000 + i) for i in range(cores)], chunksize=1)
     dt = time.time() - t0
     frames = per_proc * cores
     mse_ls = float(np.mean([p[1] for p in parts])); mse_mm = float(np.mean([p[2] for p in parts]))
@@ -161,8 +198,9 @@ def cpu_baseline(workload, budget_s=20.0):
     except Exception:
         pass
     return {"value": frames / dt, "unit": "frames/s", "cores": cores, "kind": "port", **(ratio or {"ref_ratio": None}),
+            "cpu_model": cpu_model(), "host": seen, "one_frame_one_core_s": round(one, 3),
             "est_mse": {"ls": mse_ls, "mmse": mse_mm, "frames": frames},        # same statistic as the GPU line's est_mse, other random frames
-            "sample": f"{frames} frames of {workload} ({per_proc}/process x {cores} processes), oracle faithful mode "
+            "sample": f"{frames} frames of {workload} ({per_proc}/process x {cores} processes = one per usable host core), oracle faithful mode "
                       f"(float64 NumPy/SciPy restatement with the reference's cost structure), {dt:.1f} s wall"}
 
 
@@ -300,7 +338,7 @@ class Job:
             dist.destroy_process_group()
 
 
-def measure_leg(job, args, workload, group, steps, warmup, frames=None, patterns_resident=False, cpu=False):
+def measure_leg(job, args, workload, group, steps, warmup, frames=None, patterns_resident=False):
     """One measured leg: `warmup` untimed steps, then `steps` timed steps of `workload` on every rank, barrier + synchronize on
     both sides, MAX over ranks.  Returns the result record (rank 0) or None (other ranks)."""
     import torch
@@ -516,34 +554,74 @@ def measure_leg(job, args, workload, group, steps, warmup, frames=None, patterns
         summ = torch.stack(per_snr).sum(0)
     for i in range(warmup):
         step(i)
+    # ---- the collectives of the job, warmed BEFORE t0 -------------------------------------------------------------------------------
+    # RCCL sets up its point-to-point connections lazily, on the first collective that needs them: a gather (send / recv) after
+    # nothing but barriers (all-reduces) would pay that set-up inside whatever region it runs in.  Every collective the job uses
+    # -- the gather of the metric sums, the all-gather of the per-rank times, the MAX-reduction -- runs once here, untimed.
+    def gather_sums(v):
+        parts = [torch.zeros_like(v) for _ in range(world)] if rank == 0 else None
+        dist.gather(v, parts, dst=0)
+        return parts
+
+    def all_ranks(vals):
+        v = torch.tensor(vals, dtype=torch.float64, device=coll_dev)
+        parts = [torch.zeros_like(v) for _ in range(world)]
+        dist.all_gather(parts, v)
+        return torch.stack(parts).cpu().numpy()
+
     if use_coll:
+        gather_sums(torch.zeros_like(summ.to(coll_dev)))
+        all_ranks([0.0] * 5)
+        tw = torch.zeros(1, dtype=torch.float64, device=coll_dev)
+        dist.all_reduce(tw, op=dist.ReduceOp.MAX)
         dist.barrier()
     torch.cuda.synchronize()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
     eng.profile_begin(steps * (nch if kind == "fullcov" else nrep))   # library-side HIP events around each kernel, on the launch stream
+    # ---- the timed region: EXACTLY `steps` steps between barrier + synchronize on both sides -----------------------------------
     t0 = time.perf_counter()
     for i in range(steps):
         ev[i][0].record()
         step(warmup + i)
         ev[i][1].record()
-    # the job's single collective: per-rank metric sums gathered to rank 0 (RCCL over xGMI)
-    if use_coll:
-        summ_c = summ.to(coll_dev)
-        gathered = [torch.zeros_like(summ_c) for _ in range(world)] if rank == 0 else None
-        dist.gather(summ_c, gathered, dst=0)
-        if rank == 0:
-            summ = torch.stack(gathered).sum(0)
-        dist.barrier()
     torch.cuda.synchronize()
+    dt_own = time.perf_counter() - t0                                    # this rank's own time, before it waits for the others
+    if use_coll:
+        dist.barrier()
+        torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     eng.check_status()
+    # ---- the job's single collective, timed on its own: per-rank metric sums gathered to rank 0 (RCCL over xGMI) ------------------
+    # (folded into a 40-ms timed region it would be a per-step cost the job does not have: it runs ONCE per job, however many steps)
+    collective_ms = None
     if use_coll:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
+        tc = time.perf_counter()
+        gathered = gather_sums(summ.to(coll_dev))
+        torch.cuda.synchronize()
+        collective_ms = (time.perf_counter() - tc) * 1e3
+        if rank == 0:
+            summ = torch.stack(gathered).sum(0)
+        tmax = torch.tensor([dt, collective_ms], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+        dt, collective_ms = float(tmax[0].item()), float(tmax[1].item())
     call_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))      # one step on the stream (all its kernels)
     kern = eng.profile_read_all()                                        # {kernel name: average ms per launch}
     eng.profile_begin(0)
+    # every rank's own figures beside the MAX: the write level of a process's output allocations varies by up to 25 %, so
+    # with N ranks `value` (the honest MAX) reads the slowest placement -- per_rank tells that apart from a communication loss
+    per_rank = None
+    mine = [dt_own / steps * 1e3, kern.get("frame_kernel", 0.0), kern.get("taps_kernel", 0.0), call_ms, kern.get("plan_kernels", 0.0)]
+    tab = all_ranks(mine) if use_coll else np.asarray([mine])
+    if rank == 0:
+        def _stat(col):
+            v = tab[:, col]
+            return {"min": float(v.min()), "median": float(np.median(v)), "max": float(v.max()), "argmax": int(v.argmax()),
+                    "all": [float(x) for x in v]}
+        per_rank = {"ms_per_step": _stat(0), "frame_kernel_ms": _stat(1), "taps_kernel_ms": _stat(2), "stream_ms_per_step": _stat(3),
+                    "note": "ms_per_step: each rank's own wall time over its timed steps before the closing barrier; `value` uses the MAX over "
+                            "ranks of the barrier-to-barrier time"}
+        if tab[:, 4].max() > 0:
+            per_rank["pattern_kernel_ms"] = _stat(4)
 
     res = None
     if rank == 0:
@@ -617,8 +695,14 @@ def measure_leg(job, args, workload, group, steps, warmup, frames=None, patterns
             "metric": "OFDM frames/sec (LS+MMSE)", "value": F * nrep * world * steps / dt, "unit": "frames/s",
             "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": dt / steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": cfgd, "roofline": roof,
+            "config": cfgd, "roofline": roof, "per_rank": per_rank,
         }
+        if collective_ms is not None:
+            # the end-of-job gather (once per job, not per step), MAX over ranks of the host-observed time incl. the synchronize after it
+            res["collective_ms"] = collective_ms
+            res["collective"] = {"op": "gather of the per-rank metric sums to rank 0 (4 float64 per rank)", "backend": args.dist_backend,
+                                 "ms": collective_ms, "warmed_before_timed_region": True,
+                                 "value_with_collective": F * nrep * world * steps / (dt + collective_ms * 1e-3)}
         if s[3] > 0:
             res["est_mse"] = {"ls": float(s[1] / s[3]), "mmse": float(s[2] / s[3]),
                               "nmse_db_ls": float(10 * np.log10(s[1] / s[0])), "nmse_db_mmse": float(10 * np.log10(s[2] / s[0]))}
@@ -640,13 +724,106 @@ def measure_leg(job, args, workload, group, steps, warmup, frames=None, patterns
             except Exception:
                 pass
             res["snr_sweep"] = curve
-        if cpu:
-            res["cpu_baseline"] = cpu_baseline(workload)
     # hand the leg's HBM back before the next one allocates
     del out
     eng.close()
     torch.cuda.empty_cache()
     return res
+
+
+def cubic_leg(job, frames=1024, steps=5, warmup=2):
+    """`also.ls_cubic_2x2`: LSEstimator('cubic') -- griddata(method='cubic') = Clough-Tocher, src/baseline_estimators.py:65-79 -- on
+    config 2's frames, beside the only LS timing the reference publishes (203 ms per 2x2 frame, PHASE_2_BASELINE_ESTIMATORS.md:268,
+    timed at test_phase2_comparison.py:76-78 around `ls_estimator.estimate` alone).  The pattern is shared by the batch, so its dense
+    Clough-Tocher operator A [G][P] is built ONCE outside the timed region (Qhull's triangulation from the host, everything after it on
+    the device: chest_cubic_operator); timed: chest_estimate_dense = pilot division + the real x complex product A [G x P] . h [P x B R T]
+    on v_mfma_f32_32x32x2_f32.  Bound: MFMA (4 G P flop per (frame, rx, tx) grid against the 157.3 TFLOP/s f32-matrix peak; the result
+    alone is 8 G bytes per grid, an HBM floor ~20x below the matrix time)."""
+    import torch
+    E = importlib.import_module(PKG + ".engine")
+    IP = importlib.import_module(PKG + ".interp_plan")
+    w = WORKLOADS["cfg2_2x2_eva_ls_mmse"]
+    T, R = w["T"], w["R"]
+    geom = E.Geometry(fft_size=w["N"], cp_length=w["cp"], num_symbols=14, useful_subcarriers=w["U"], num_tx=T, num_rx=R)
+    eng = E.Engine(geom, job.local)
+    S, nsc, G = geom.num_symbols, geom.num_sc, geom.grid
+    P = int(G * w["dens"])
+    slot0 = int(eng.build_patterns(0, np.asarray([P], np.int32), seed=2024, pattern_ids=np.asarray([0], np.uint64), method=None)[0])
+    pil = eng.get_pilots(slot0)
+    ps, pk = np.unravel_index(pil.astype(np.int64), (S, nsc))
+    t0 = time.perf_counter()
+    simp, nbr = IP.delaunay_with_neighbors(ps, pk)
+    t_qhull = time.perf_counter() - t0
+    slot = eng.pattern_slot(pil, "linear", plan=simp)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    A = eng.cubic_operator_from_triangulation(slot, simp, nbr)
+    torch.cuda.synchronize(); t_build = time.perf_counter() - t0
+    d = E.make_descs(w["ct"], w["fd"], w["snr"], slot, n=frames)
+    sim = eng.run_frames(d, seed=2024, outputs=("rx", "pilot_symbols", "H"))
+    rx4 = sim["rx"][:, :, :, None, :].expand(frames, S, R, T, nsc).contiguous()      # the callers' rx_4d (src/dataset_generator.py:63-64)
+    xp = sim["pilot_symbols"][:, :P].contiguous()
+    for _ in range(warmup):
+        out = eng.estimate_dense(rx4, xp, slot, A)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(steps):
+        out = eng.estimate_dense(rx4, xp, slot, A)
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / steps
+    es = eng.error_sums(sim["H"], out).cpu().numpy()
+    flop = 4.0 * G * P * R * T * frames
+    rec = {"value": frames / dt, "unit": "LS('cubic') estimates of a 2x2 frame per second", "ms_per_step": dt * 1e3, "ms_per_frame": dt * 1e3 / frames,
+           "frames_per_step": frames, "pilots": P, "bound": "mfma", "achieved_TFLOPs": flop / dt / 1e12, "peak": MFMA_F32_PEAK_TFLOPS,
+           "frac": flop / dt / 1e12 / MFMA_F32_PEAK_TFLOPS, "flop_note": "4 G P per (frame, rx, tx) grid: real operator x complex right-hand sides, f32 MFMA",
+           "operator_build": {"qhull_host_ms": t_qhull * 1e3, "device_ms": t_build * 1e3, "inside_timed_region": False},
+           "timed": "chest_estimate_dense only (what the reference's 203 ms times: LSEstimator.estimate); scratch allocation included",
+           "reference_published_ms_per_frame": 203.0, "reference_source": "PHASE_2_BASELINE_ESTIMATORS.md:268,293 (unspecified hardware)",
+           "est_mse_ls_cubic": float(es[0] / sim["H"].numel()), "triangulation": "qhull"}
+    del sim, rx4, out, A
+    eng.close()
+    torch.cuda.empty_cache()
+    return rec
+
+
+def dropin_leg(job, frames=40, warmup=5):
+    """`also.dropin_single_frame`: the reference-named single-frame API, NumPy in / NumPy out, one call per frame as the reference's
+    scripts make them -- simulate_transmission + LSEstimator('cubic').estimate + MMSEEstimator().estimate (the two estimators
+    test_phase2_comparison.py:76-99 times: 203 ms / 588 ms per 2x2 frame) + LSEstimator('linear').estimate.  PCIe, host RNG replay, a
+    new pilot pattern (Qhull on the host) per frame all included: this is latency of the drop-in, never `value`."""
+    cs = importlib.import_module(PKG + ".channel_simulator")
+    be = importlib.import_module(PKG + ".baseline_estimators")
+    cfg = {"ofdm": {"fft_size": 1024, "cp_length": 72, "num_symbols": 14, "useful_subcarriers": 600, "subcarrier_spacing": 15000.0},
+           "mimo": {"num_tx_antennas": 2, "num_rx_antennas": 2}, "channel": {"carrier_freq": 2e9}}
+    ls_c, ls_l, mm = be.LSEstimator("cubic"), be.LSEstimator("linear"), be.MMSEEstimator()
+    np.random.seed(42)
+    t = np.zeros(4)
+
+    def frame():
+        t0 = time.perf_counter()
+        r = cs.simulate_transmission(cfg, "EVA", 111.1, 10, 0.1)
+        t1 = time.perf_counter()
+        rx4 = np.repeat(r["rx_symbols"][:, :, None, :], 2, axis=2)
+        pp = r["pilot_pattern"]
+        pos = pp.get_pilot_positions()
+        t1b = time.perf_counter()
+        ls_c.estimate(rx4, r["pilot_symbols"], pp.pilot_mask, pos)
+        t2 = time.perf_counter()
+        mm.estimate(rx4, r["pilot_symbols"], pp.pilot_mask, pos, snr_db=10)
+        t3 = time.perf_counter()
+        ls_l.estimate(rx4, r["pilot_symbols"], pp.pilot_mask, pos)
+        t4 = time.perf_counter()
+        return np.asarray([t1 - t0, t2 - t1b, t3 - t2, t4 - t3])
+
+    for _ in range(warmup):
+        frame()
+    for _ in range(frames):
+        t += frame()
+    t = t / frames * 1e3
+    return {"frames": frames, "ms_simulate_transmission": float(t[0]), "ms_ls_cubic_estimate": float(t[1]), "ms_mmse_estimate": float(t[2]),
+            "ms_ls_linear_estimate": float(t[3]),
+            "reference_published_ms": {"ls_cubic_estimate": 203.0, "mmse_estimate": 588.0,
+                                       "source": "PHASE_2_BASELINE_ESTIMATORS.md:268,293; test_phase2_comparison.py:76-99 (unspecified hardware)"},
+            "speedup_vs_published": {"ls_cubic_estimate": 203.0 / float(t[1]), "mmse_estimate": 588.0 / float(t[2])},
+            "note": "2x2, EVA 111.1 Hz, 10 dB, 10 % pilots; a NEW pilot pattern per frame (Qhull + plan / Clough-Tocher operator built per call), "
+                    "NumPy in / NumPy out (PCIe both ways), legacy np.random replay on the host"}
 
 
 def _brief(res):
@@ -696,7 +873,7 @@ def run(args):
     quiet = _QuietStdout()
     job = Job(args)
     res = measure_leg(job, args, args.workload, args.pattern_group, args.steps, args.warmup, frames=args.frames,
-                      patterns_resident=args.patterns_resident, cpu=job.world == 1 and not args.no_cpu_baseline)
+                      patterns_resident=args.patterns_resident)
     # The default invocation (what the driver runs: BASELINE config 2, shared patterns, one GPU) also measures, after the main
     # timed region: the same workload with the reference's own semantics -- a NEW pilot pattern per frame, drawn, triangulated
     # and planned on the device inside every timed step (src/channel_simulator.py:390-391, src/baseline_estimators.py:65-79) --
@@ -737,9 +914,22 @@ def run(args):
             rec, err = leg(name, grp, 5, 2)
             if job.rank == 0:
                 also[name] = _brief(rec) if rec is not None else {"error": err}
+        # the two figures the reference itself publishes for this path: LS ('cubic') and MMSE time per 2x2 frame
+        for name, fn in (("ls_cubic_2x2", cubic_leg), ("dropin_single_frame", dropin_leg)):
+            try:
+                also[name] = fn(job)
+            except Exception as e:                                           # noqa: BLE001 -- reported in place of the record
+                import traceback
+                traceback.print_exc(file=sys.stderr)
+                torch.cuda.empty_cache()
+                also[name] = {"error": f"{type(e).__name__}: {e}"}
         if job.rank == 0:
             res["also"] = also
     job.close()
+    # The CPU path beside the GPU number, in the same run, at EVERY N (north_star): rank 0 times it on the host cores after the
+    # job -- outside every timed region, the process group already gone, the other ranks exiting.
+    if job.rank == 0 and not args.no_cpu_baseline:
+        res["cpu_baseline"] = cpu_baseline(args.workload, budget_s=args.cpu_budget_s)
     quiet.restore()
     if job.rank == 0:
         print(json.dumps(res), flush=True)
@@ -773,6 +963,7 @@ def main():
                     help="cfg5: chunks of the batch pipelined over three streams (frame kernel | MFMA filter | interpolation); 1 = in sequence")
     ap.add_argument("--single-snr", action="store_true", help="cfg3: one launch at SNR 10 dB per step instead of the eight-point sweep")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget-s", type=float, default=15.0, help="wall-time budget of the cpu_baseline sample (one process per usable host core)")
     ap.add_argument("--no-extra-legs", action="store_true",
                     help="default invocation only: skip the per_frame_patterns leg and the `also` legs of the other workloads")
     ap.add_argument("--rccl-rehearsal", action="store_true",

@@ -128,23 +128,44 @@ class MMSEEstimator:
     def _uses_diagonal(self):
         return self.estimate_statistics or self.channel_covariance is None
 
+    @staticmethod
+    def _odd_weights(n, salt):
+        """n odd 64-bit constants (splitmix64 of the position): multiplication by an odd number is invertible mod 2^64."""
+        x = (np.arange(n, dtype=np.uint64) + np.uint64(salt)) * np.uint64(0x9E3779B97F4A7C15)
+        x ^= x >> np.uint64(30); x *= np.uint64(0xBF58476D1CE4E5B9)
+        x ^= x >> np.uint64(27); x *= np.uint64(0x94D049BB133111EB)
+        x ^= x >> np.uint64(31)
+        return x | np.uint64(1)
+
     def _cov_fingerprint(self, cov):
-        """Cheap CONTENT-derived identity of the covariance, checked on every call: every entry contributes (an in-place edit of
-        any single entry, through any view, changes it; so does a new object at a recycled id / storage address).  Array: the
-        row sums and column sums of the buffer read as uint64 words (two passes at memory bandwidth, ~10 ms at P = 1 678,
-        against ~50 ms for the cryptographic hash of the 45 MB); tensor: row and column sums of its real view in float64, reduced
-        on the device, 2 P numbers copied back.  The full content hash is computed only when this changes."""
+        """Cheap CONTENT-derived identity of the covariance, checked on every call.  The buffer is read as integer words (bit
+        patterns, so no floating-point absorption) and every row is reduced to sum_j word[i][j] * b_j mod 2^64 with odd
+        per-column constants b_j; the P row checksums are hashed.  An in-place edit of any single word changes its row's
+        checksum (odd multipliers are invertible mod 2^64) and edits in different rows cannot cancel each other; what CAN
+        collide is a set of two or more edits inside one row whose weighted differences sum to 0 mod 2^64 -- a 2^-64 accident,
+        not a pattern such as a +d / -d rectangle.  It is a checksum, not a cryptographic hash: the full content hash is
+        computed only when this fingerprint changes.  ndarray: one pass over the buffer on the host (~20 ms at P = 1 678);
+        tensor: the same integer arithmetic on the device, P words copied back."""
         import hashlib
         if _is_tensor(cov):
             v = torch.view_as_real(cov) if cov.is_complex() else cov
-            v = v.reshape(cov.shape[0], -1).to(torch.float64) if cov.dim() >= 1 and cov.numel() else v.reshape(1, -1).to(torch.float64)
-            sums = torch.cat([v.sum(dim=0), v.sum(dim=1), (v * v).sum().reshape(1)]).cpu().numpy()
+            v = v.contiguous()
+            rows = int(cov.shape[0]) if cov.dim() >= 1 and cov.numel() else 1
+            if v.element_size() == 8:
+                w = v.view(torch.int64).reshape(rows, -1)
+            elif v.element_size() == 4:
+                w = v.view(torch.int32).reshape(rows, -1).to(torch.int64)
+            else:
+                w = v.to(torch.float64).view(torch.int64).reshape(rows, -1)
+            b = torch.from_numpy(self._odd_weights(w.shape[1], 1).view(np.int64)).to(w.device)
+            sums = (w * b).sum(dim=1).cpu().numpy()                      # int64 arithmetic wraps: mod 2^64
             return ("t", tuple(cov.shape), str(cov.dtype), hashlib.blake2b(sums.tobytes(), digest_size=16).digest())
         a = np.asarray(cov)
         c = a if a.flags.c_contiguous else np.ascontiguousarray(a)
         if c.ndim == 2 and c.size and (c.shape[1] * c.itemsize) % 8 == 0:
             w = c.view(np.uint64).reshape(c.shape[0], -1)
-            sums = np.concatenate([w.sum(axis=0, dtype=np.uint64), w.sum(axis=1, dtype=np.uint64)])
+            with np.errstate(over="ignore"):
+                sums = (w * self._odd_weights(w.shape[1], 1)[None, :]).sum(axis=1, dtype=np.uint64)
             digest = hashlib.blake2b(sums.tobytes(), digest_size=16).digest()
         else:
             digest = hashlib.blake2b(c.tobytes(), digest_size=16).digest()

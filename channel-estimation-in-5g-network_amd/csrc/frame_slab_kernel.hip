@@ -780,15 +780,26 @@ frame_slab_kernel(const FrameParams* __restrict__ fpp, const chest_frame_desc* _
     const int S = fp.S, T = fp.T, R = fp.R, G = fp.G;
     const float* rec = state + (size_t)b * frame_state_floats(S, R, T);
     const chest_frame_desc fd = descs[b];
-    if (rec[ST_VALID] == 0.f) return;                            // K1 flagged the descriptor (uniform exit)
+    // A failed frame leaves its outputs untouched (chest.h) -- except its rows of h_ls_pilots, which are written as zeros: the
+    // full-covariance filter reads that tensor as ONE GEMM operand (scaled by its largest magnitude), so whatever an uninitialised
+    // allocation held there would reach the other frames' results.
+    auto fail_frame = [&]() {
+        if (out.h_ls_pilots != nullptr) {
+            float2* hl = (float2*)out.h_ls_pilots + (size_t)b * R * out.h_ls_stride;
+            for (int i = tid; i < R * out.h_ls_stride; i += blockDim.x) hl[i] = make_float2(0.f, 0.f);
+        }
+    };
+    if (rec[ST_VALID] == 0.f) { fail_frame(); return; }          // K1 flagged the descriptor (uniform exit)
     const PatternDev pat = patterns[fd.pattern_slot];
     if (pat.slot == nullptr) {
         if (tid == 0) { atomicExch(status, 1); if (out.frame_status) out.frame_status[b] = 1; }
+        fail_frame();
         return;
     }
     const bool want_est = out.H_ls != nullptr || out.H_mmse != nullptr || out.metrics != nullptr;
     if (want_est && (pat.plan == nullptr || (pat.pad != 0) != CP)) {       // no plan, or not in the format this launch reads
         if (tid == 0) { atomicExch(status, 2); if (out.frame_status) out.frame_status[b] = 2; }
+        fail_frame();
         return;
     }
     const int P = pat.P;
@@ -905,9 +916,11 @@ template <int MAXTHR, int MINW, int TT, int RR, int RGT, int SS, bool INJ, bool 
 static int launch_one(chest_ctx* ctx, int which, hipStream_t st, dim3 grid, dim3 block, size_t lds, const chest_frame_desc* descs, int Pmax,
                       uint64_t seed, uint64_t frame_offset, const chest_injected& inj, const chest_frame_outputs& out,
                       const float* workspace, int RG) {
+    if ((int)block.x > MAXTHR) { set_error("frame kernel: a %u-thread workgroup for an instantiation built for %d", block.x, MAXTHR); return CHEST_EINVAL; }
     CHEST_LDS_OPT_IN(ctx, which, (frame_slab_kernel<MAXTHR, MINW, TT, RR, RGT, SS, INJ, CP, MF>), lds);
     hipLaunchKernelGGL((frame_slab_kernel<MAXTHR, MINW, TT, RR, RGT, SS, INJ, CP, MF>), grid, block, lds, st, ctx->d_fp, descs, ctx->d_patterns, Pmax,
                        seed, frame_offset, inj, out, workspace, RG, ctx->d_status);
+    CHEST_HIP(hipGetLastError());
     return CHEST_OK;
 }
 
@@ -945,7 +958,7 @@ int launch_k2_slab(chest_ctx* ctx, hipStream_t st, int32_t B, const chest_frame_
     // One workgroup per CU (more than 80 KB... or 10 waves) and no estimates: a SECOND slab + two dedicated store waves let the store
     // stream of unit u run beside the synthesis of unit u + 1 (slab_body).  chest_tune "frame_two_slabs" -1 switches it off (A/B).
     bool two_slabs = false;
-    if (!want_est && !injected && nwave == 10 && fp.T == 4 && fp.R == 4 && RG == 1 && ctx->tune_two_slabs >= 0 && ctx->tune_store_extra >= 0) {
+    if (!want_est && !injected && !(fp.half & 1) && nwave == 10 && fp.T == 4 && fp.R == 4 && RG == 1 && ctx->tune_two_slabs >= 0 && ctx->tune_store_extra >= 0) {
         const size_t extra = (size_t)((slab_elems(fp.T, RG, fp.nsc, 1, false) + 1) & ~1) * sizeof(float2);
         if (lds + extra <= 160 * 1024) { lds += extra; two_slabs = true; nsx = ctx->tune_store_extra > 0 ? (ctx->tune_store_extra > 4 ? 4 : ctx->tune_store_extra) : 2; }
     }

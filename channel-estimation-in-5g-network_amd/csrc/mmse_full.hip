@@ -184,9 +184,20 @@ __device__ __forceinline__ float h2_scale(float amax) {
     return ldexpf(1.0f, e);                                  //  scales and its reciprocal stay finite; such operands lose precision, not sign)
 }
 
-// largest |x[i]| of a contiguous, 16-B aligned float array (pad entries inside it are zeros): eight float4 loads in flight per thread
+// largest FINITE |x[i]| of a contiguous, 16-B aligned float array (pad entries inside it are zeros): eight float4 loads in flight per
+// thread.  NaN / Inf entries do not take part in the scale (the GEMM still propagates them into the rows they belong to).
+__device__ __forceinline__ float finite_abs(float v) { const float a = fabsf(v); return a < __builtin_inff() ? a : 0.f; }   // (NaN compares false)
+__device__ __forceinline__ float absmax4(float m, const float4 v) {
+    return fmaxf(m, fmaxf(fmaxf(finite_abs(v.x), finite_abs(v.y)), fmaxf(finite_abs(v.z), finite_abs(v.w))));
+}
+// blockIdx.y selects a segment of `seg` floats (a multiple of 4) starting at x + blockIdx.y * seg and its own result word out[blockIdx.y]
+// (the last segment ends at n): the filter's right-hand sides get ONE SCALE PER 128-ROW GEMM TILE, so a row's fp16 split depends on the
+// rows of its own tile only -- an absurd value in one frame cannot flush the other tiles' operands to zero.
 __global__ void __launch_bounds__(256)
-absmax_kernel(size_t n, const float* __restrict__ x, unsigned* __restrict__ out) {
+absmax_kernel(size_t n, size_t seg, const float* __restrict__ x, unsigned* __restrict__ out) {
+    const size_t lo = (size_t)blockIdx.y * seg;
+    if (lo >= n) return;
+    x += lo; n = n - lo < seg ? n - lo : seg;
     float m = 0.f;
     const size_t n4 = n >> 2, stride = (size_t)gridDim.x * blockDim.x;
     const float4* x4 = (const float4*)x;
@@ -196,13 +207,13 @@ absmax_kernel(size_t n, const float* __restrict__ x, unsigned* __restrict__ out)
 #pragma unroll
         for (int u = 0; u < 8; ++u) v[u] = x4[i + u * stride];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) m = fmaxf(m, fmaxf(fmaxf(fabsf(v[u].x), fabsf(v[u].y)), fmaxf(fabsf(v[u].z), fabsf(v[u].w))));   // (fmaxf drops a NaN; the GEMM propagates it)
+        for (int u = 0; u < 8; ++u) m = absmax4(m, v[u]);
     }
-    for (; i < n4; i += stride) { const float4 v = x4[i]; m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)))); }
-    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) m = fmaxf(m, fabsf(x[(n4 << 2) + threadIdx.x]));
+    for (; i < n4; i += stride) m = absmax4(m, x4[i]);
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) m = fmaxf(m, finite_abs(x[(n4 << 2) + threadIdx.x]));
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
-    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(out, __float_as_uint(m));      // non-negative floats order like their bit patterns
+    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(out + blockIdx.y, __float_as_uint(m));      // non-negative floats order like their bit patterns
 }
 
 // X [rows][ld] complex64 (valid: nr rows x P columns) -> packed fp16 planes (layout above).  Workgroup (row tile, chunk of k stages):
@@ -277,7 +288,7 @@ cgemm_w_kernel_h2(int P, int Kpad, int M, int ldo, const _Float16* __restrict__ 
     // half tid & 1) fetches its 8 complex values of a stage = 64 B; two threads cover 128 contiguous bytes of a row
     const u4_t* gh = (const u4_t*)(Hf + (size_t)(m0 + (tid >> 1)) * lda + (tid & 1) * 8);
     const u4_t* gw = (const u4_t*)(Wq + (size_t)bx * nks * 6 * 128 * 16) + tid;
-    const float sh = h2_scale(__uint_as_float(*amax_h));
+    const float sh = h2_scale(__uint_as_float(amax_h[by]));     // one scale per 128-row tile of right-hand sides (absmax_kernel)
     const unsigned st_off = (unsigned)((tid >> 1) * H2_ROWB + (tid & 1) * 16);
     // fragment of a 32-row tile: lane l holds row (l & 31), k = 8 (l >> 5) ... + 7: one 16-B read
     const unsigned fr_off = (unsigned)((lane & 31) * H2_ROWB + (lane >> 5) * 16);
@@ -571,6 +582,7 @@ pack_a_kernel(int G, int P, int Kpad, const float* __restrict__ A, float* __rest
 
 static inline int pad16(int p) { return (p + 15) & ~15; }
 static inline int pad128(int p) { return (p + 127) & ~127; }
+static inline int64_t amax_h_bytes(int M) { return (((int64_t)pad128(M) / 128) * 4 + 63) & ~(int64_t)63; }   // per-tile maxima of the right-hand sides
 
 }  // namespace chest
 
@@ -611,9 +623,9 @@ int chest_mmse_full_prepare(chest_ctx* ctx, void* stream, int32_t P, const doubl
 int64_t chest_mmse_full_apply_scratch_bytes(int32_t P, int32_t num_grids) {
     if (P <= 0 || num_grids <= 0) return 0;
     const int64_t Ppad = pad16(P);
-    // h_in [Mpad][Ppad] c64 | h_out [M][Ppad] c64 | Hq: six fp16 planes [Mpad][Ppad] | Wq: six fp16 planes [Npad][Ppad] (the f32 path's
-    // packed W [Npad][Ppad] c64 lives there too) | the two operand maxima
-    return Ppad * ((int64_t)sizeof(float2) * (pad128(num_grids) + num_grids) + 12 * ((int64_t)pad128(num_grids) + pad128(P))) + 64;
+    // h_in [Mpad][Ppad] c64 | h_out [M][Ppad] c64 | Wq: six fp16 planes [Npad][Ppad] (the f32 path's packed W [Npad][Ppad] c64 needs
+    // 8 of those 12 bytes per entry) | 16 words: the filter's largest magnitude | one word per 128-row tile: the right-hand sides' maxima
+    return Ppad * ((int64_t)sizeof(float2) * (pad128(num_grids) + num_grids) + 12 * (int64_t)pad128(P)) + 64 + amax_h_bytes(num_grids);
 }
 
 // W h for M right-hand sides on the matrix pipe.  h_src [M][h_ld] complex64 (rows beyond M and columns beyond P are taken as zero).
@@ -624,9 +636,9 @@ static int launch_w_gemm(chest_ctx* ctx, hipStream_t st, int P, int M, const flo
     const int Ppad = pad16(P), Mpad = pad128(M), Npad = pad128(P);
     float2* h_in = (float2*)h_scratch;
     float2* h_out = h_in + (size_t)Mpad * Ppad;
-    _Float16* Hq = (_Float16*)(h_out + (size_t)M * Ppad);
-    _Float16* Wq = Hq + (size_t)6 * Mpad * Ppad;
-    unsigned* amax = (unsigned*)(Wq + (size_t)6 * Npad * Ppad);
+    _Float16* Wq = (_Float16*)(h_out + (size_t)M * Ppad);
+    unsigned* amax = (unsigned*)(Wq + (size_t)6 * Npad * Ppad);      // [0]: the filter's maximum; [16 ...]: one per row tile of h
+    unsigned* amax_h = amax + 16;
     if (ctx->tune_gemm_f32) {
         if (Wpacked != nullptr) { set_error("a packed filter is read by the fp16-split kernel only (chest_tune gemm_f32 is set)"); return CHEST_ESTATE; }
         float2* w_packed = (float2*)Wq;
@@ -649,7 +661,7 @@ static int launch_w_gemm(chest_ctx* ctx, hipStream_t st, int P, int M, const flo
     const float2* h_op = h_src;
     int h_op_ld = h_ld;
     if (!h_src_is_packed_f32) { hipLaunchKernelGGL(pack_h_kernel, dim3(Mpad), dim3(256), 0, st, M, P, h_ld, Ppad, h_src, h_in); h_op = h_in; h_op_ld = Ppad; }
-    CHEST_HIP(hipMemsetAsync(amax, 0, 64, st));
+    CHEST_HIP(hipMemsetAsync(amax, 0, 64 + (size_t)amax_h_bytes(M), st));
     if (Wpacked == nullptr && ((uintptr_t)W & 15) != 0) { set_error("W must be a 16-byte aligned device pointer"); return CHEST_EINVAL; }
     const _Float16* Wq_use = Wq;
     const unsigned* amax_w = amax;
@@ -657,15 +669,17 @@ static int launch_w_gemm(chest_ctx* ctx, hipStream_t st, int P, int M, const flo
         Wq_use = (const _Float16*)Wpacked;
         amax_w = (const unsigned*)((const unsigned char*)Wpacked + (size_t)12 * Npad * Ppad);
     } else {
-        hipLaunchKernelGGL(absmax_kernel, dim3(256), dim3(256), 0, st, (size_t)2 * P * P, (const float*)W, amax);
+        hipLaunchKernelGGL(absmax_kernel, dim3(256), dim3(256), 0, st, (size_t)2 * P * P, (size_t)2 * P * P, (const float*)W, amax);
         hipLaunchKernelGGL(pack_h2_kernel, dim3(Npad / 128, (Ppad / 16 + H2_PACK_KS - 1) / H2_PACK_KS), dim3(256), 0, st, P, P, P, Ppad, W, amax, Wq);
     }
-    hipLaunchKernelGGL(absmax_kernel, dim3(1024), dim3(256), 0, st, (size_t)2 * M * h_op_ld, (const float*)h_op, amax + 1);   // (zero pads inside)
+    // (rows m0 .. m0 + 127 of the operand are 256 * h_op_ld contiguous floats, zero pads inside; 16 workgroups per tile)
+    hipLaunchKernelGGL(absmax_kernel, dim3(16, (unsigned)(Mpad / 128)), dim3(256), 0, st, (size_t)2 * M * h_op_ld, (size_t)256 * h_op_ld,
+                       (const float*)h_op, amax_h);
     prof_close(ctx, st, sp_pack);
     CHEST_LDS_OPT_IN(ctx, LDS_GEMM, cgemm_w_kernel_h2, H2_LDS_BYTES);
     const int sp_gemm = prof_open(ctx, st, CHEST_K_GEMM);
     hipLaunchKernelGGL(cgemm_w_kernel_h2, dim3((((Npad / T2_N) * (Mpad / T2_M) + 7) / 8) * 8), dim3(256), H2_LDS_BYTES, st, P, Ppad, M, Ppad,
-                       Wq_use, h_op, h_op_ld, amax_w, (const unsigned*)(amax + 1), h_out);
+                       Wq_use, h_op, h_op_ld, amax_w, (const unsigned*)amax_h, h_out);
     prof_close(ctx, st, sp_gemm);
     CHEST_HIP(hipGetLastError());
     return CHEST_OK;
@@ -753,7 +767,7 @@ int chest_mmse_full_pack_filter(chest_ctx* ctx, void* stream, int32_t P, const f
     const int Ppad = pad16(P), Npad = pad128(P);
     unsigned* amax = (unsigned*)((unsigned char*)packed + (size_t)12 * Npad * Ppad);
     CHEST_HIP(hipMemsetAsync(amax, 0, 64, st));
-    hipLaunchKernelGGL(absmax_kernel, dim3(256), dim3(256), 0, st, (size_t)2 * P * P, W, amax);
+    hipLaunchKernelGGL(absmax_kernel, dim3(256), dim3(256), 0, st, (size_t)2 * P * P, (size_t)2 * P * P, W, amax);
     hipLaunchKernelGGL(pack_h2_kernel, dim3(Npad / 128, (Ppad / 16 + H2_PACK_KS - 1) / H2_PACK_KS), dim3(256), 0, st, P, P, P, Ppad,
                        (const float2*)W, amax, (_Float16*)packed);
     CHEST_HIP(hipGetLastError());

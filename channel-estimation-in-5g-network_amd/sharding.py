@@ -4,7 +4,8 @@ Frames are independent: every random draw of frame i is a pure function of (seed
 contiguous split of [0, total) over the ranks produces exactly the frames a single GPU would
 (reference loop: src/dataset_generator.py:112-125, which is sequential only because it shares one
 global RNG).  There is no collective on the data path; the job ends with ONE gather of the small
-per-frame metadata / metric records (36 + 8 bytes per frame, one packed block per rank) to rank 0.
+per-frame metadata / metric records (36 + 8 bytes per frame, one packed block per rank) to rank 0, preceded by its
+16-byte header exchange (record count and capacity of every rank).
 """
 from __future__ import annotations
 
@@ -43,16 +44,17 @@ def frame_choices(seed: int, frame_index: np.ndarray, num_options):
 
 def gather_records(local: "np.ndarray", frame_index: "np.ndarray" = None, dst: int = 0, all_ranks: bool = False, group=None,
                    capacity: int = None, force_collective: bool = False, total: int = None):
-    """The job's single collective: every rank's per-frame records (float32 [n_local, C]) together with their GLOBAL frame
+    """The job's single payload collective: every rank's per-frame records (float32 [n_local, C]) together with their GLOBAL frame
     indices (int64: float32 is exact only below 2^24 frames), concatenated in rank order.
 
-    ONE collective carries everything: each rank sends an int32 block [capacity + 1, C + 2] -- row 0 holds its record count,
-    the rows after it the float32 records bit-cast to int32 (the transport moves bytes, it does no arithmetic) followed by the
-    low and high halves of the frame index.  ``capacity`` is the largest shard size; jobs that shard with ``shard_range``
-    know it without talking (``ceil(total / world)``): they pass ``total`` (the job's record count; the capacity is then derived
-    from the size of the GROUP the collective runs in) or ``capacity`` itself.  Without either the sizes are agreed by one extra
-    8-byte all-gather first.  A rank holding more than the capacity still enters the collective (sentinel count, no payload) and
-    raises after it, together with every rank that receives the blocks: nobody is left waiting.
+    Each rank sends ONE int32 block [capacity, C + 2]: the float32 records bit-cast to int32 (the transport moves bytes, it does
+    no arithmetic) followed by the low and high halves of the frame index.  The block is preceded by a 16-byte header exchange
+    (an all-gather of (record count, stated capacity) per rank): from it EVERY rank learns every shard size, so the payload
+    shapes agree by construction and a rank holding more records than the capacity it was told, or ranks that were told
+    different capacities, make every rank of the group raise the same ``ValueError`` BEFORE the payload collective -- nobody is
+    left waiting in a mismatched collective and nobody walks on into the next one alone.  ``capacity`` is the largest shard
+    size; jobs that shard with ``shard_range`` pass ``total`` (the job's record count; the capacity is ``ceil(total / world)`` of
+    the GROUP the collective runs in) or ``capacity`` itself; without either the header's largest count is used.
 
     Default: a ``gather`` to rank ``dst`` -- ``dst`` is a rank OF ``group`` (the default group: the global rank) -- the
     other ranks get ``(None, None)``.  ``all_ranks=True`` makes it an ``all_gather``.  Works on CPU (gloo) and GPU
@@ -77,21 +79,21 @@ def gather_records(local: "np.ndarray", frame_index: "np.ndarray" = None, dst: i
     n_local, width = local.shape
     if capacity is None and total is not None:
         capacity = -(-int(total) // world)
-    if capacity is None:
-        n = torch.tensor([n_local], dtype=torch.int64, device=dev)
-        sizes = [torch.zeros_like(n) for _ in range(world)]
-        dist.all_gather(sizes, n, group=group)                           # 8 bytes per rank, only when the caller cannot say
-        capacity = max(int(c.item()) for c in sizes)
-    # A rank whose records do not fit the stated capacity must NOT raise before the collective (the others would wait in it
-    # until the timeout): it enters with the sentinel count -1 and no payload, and raises after it -- as does every rank that
-    # receives the blocks.  Row 0 also carries the capacity the rank was told, so that ranks disagreeing about it are named.
-    overflow = n_local > capacity
-    block = np.zeros((capacity + 1, width + 2), dtype=np.int32)
-    block[0, 0] = -1 if overflow else n_local
-    block[0, 1] = capacity
-    if not overflow:
-        block[1:n_local + 1, :width] = np.ascontiguousarray(local).view(np.int32)
-        block[1:n_local + 1, width:] = np.ascontiguousarray(ids).view(np.int32).reshape(-1, 2)     # little endian: low, high
+    # header: (record count, stated capacity or -1) of every rank, 16 bytes each
+    head = torch.tensor([n_local, -1 if capacity is None else int(capacity)], dtype=torch.int64, device=dev)
+    heads_t = [torch.zeros_like(head) for _ in range(world)]
+    dist.all_gather(heads_t, head, group=group)
+    heads = [tuple(int(v) for v in h.cpu().tolist()) for h in heads_t]
+    counts, caps = [h[0] for h in heads], [h[1] for h in heads]
+    if len(set(caps)) != 1:                                                  # the same test, the same outcome, on every rank
+        raise ValueError(f"ranks disagree about the capacity: {caps}")
+    capacity = max(counts) if caps[0] < 0 else caps[0]
+    bad = [r for r, c in enumerate(counts) if c > capacity]
+    if bad:
+        raise ValueError(f"rank(s) {bad} hold more records ({[counts[r] for r in bad]}) than the stated capacity {capacity}")
+    block = np.zeros((max(capacity, 1), width + 2), dtype=np.int32)
+    block[:n_local, :width] = np.ascontiguousarray(local).view(np.int32)
+    block[:n_local, width:] = np.ascontiguousarray(ids).view(np.int32).reshape(-1, 2)     # little endian: low, high
     send = torch.from_numpy(block).to(dev)
     if all_ranks:
         parts = [torch.zeros_like(send) for _ in range(world)]
@@ -102,21 +104,12 @@ def gather_records(local: "np.ndarray", frame_index: "np.ndarray" = None, dst: i
         # torch's gather takes the GLOBAL rank of the destination
         dist.gather(send, parts, dst=dist.get_global_rank(group, dst) if group is not None else dst, group=group)
         if not root:
-            if overflow:
-                raise ValueError(f"{n_local} local records exceed the stated capacity {capacity} (rank {rank})")
             return None, None
-    heads = [p[0, :2].cpu().numpy() for p in parts]
-    bad = [r for r, h in enumerate(heads) if int(h[0]) < 0]
-    if bad:
-        raise ValueError(f"rank(s) {bad} hold more records than the stated capacity {capacity}")
-    if any(int(h[1]) != capacity for h in heads):
-        raise ValueError(f"ranks disagree about the capacity: {[int(h[1]) for h in heads]}")
     recs, idl = [], []
-    for p in parts:
-        b = p.cpu().numpy()
-        c = int(b[0, 0])
-        recs.append(np.ascontiguousarray(b[1:c + 1, :width]).view(np.float32))
-        idl.append(np.ascontiguousarray(b[1:c + 1, width:]).view(np.int64).reshape(-1))
+    for p_, c in zip(parts, counts):
+        b = p_.cpu().numpy()
+        recs.append(np.ascontiguousarray(b[:c, :width]).view(np.float32))
+        idl.append(np.ascontiguousarray(b[:c, width:]).view(np.int64).reshape(-1))
     return np.concatenate(recs).reshape(-1, width), np.concatenate(idl)
 
 

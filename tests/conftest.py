@@ -57,6 +57,53 @@ def relerr(a, b):
     return float(np.max(np.abs(a - b)) / max(float(np.max(np.abs(b))), 1e-300))
 
 
+def elementwise(a, b, rtol=1e-5, floor=1e-6):
+    """Element-wise form of the parity bound (BASELINE.md 3 says "per element"): returns
+      worst  = max over elements of |a - b| / (rtol |b| + floor max|b|)   -- the mixed bound holds iff worst <= 1
+      frac   = fraction of elements with |a - b| > rtol |b|               -- the PURE per-element relative form
+      n      = number of elements.
+    complex64 results carry ~6e-8 max|b| of absolute rounding from sums of O(max|b|) terms, so an element whose own magnitude is
+    below ~6e-3 of the tensor's scale (a deep fade, a zero outside the pilots' hull that the reference computes as 1e-17) cannot
+    meet the pure form in float32 whatever the kernel does; `floor` max|b| is the absolute part that admits exactly those."""
+    a = np.asarray(a)
+    b = np.asarray(b)
+    d = np.abs(a - b)
+    mag = np.abs(b)
+    scale = max(float(mag.max()), 1e-300)
+    worst = float(np.max(d / (rtol * mag + floor * scale)))
+    frac = float(np.count_nonzero(d > rtol * mag)) / max(1, d.size)
+    return worst, frac, int(d.size)
+
+
+ELEMENTWISE_LOG = []          # (fixture, tensor, worst mixed ratio, fraction failing the pure form, elements): written at session end
+
+
+def pytest_sessionfinish(session, exitstatus):
+    if not ELEMENTWISE_LOG:
+        return
+    import json
+    out = os.path.join(ROOT, "gpurun_out")
+    try:
+        os.makedirs(out, exist_ok=True)
+        by = {}
+        for fx, name, worst, frac, n in ELEMENTWISE_LOG:
+            t = by.setdefault(name, {"elements": 0, "failing_pure_1e-5": 0.0, "worst_mixed_ratio": 0.0, "worst_fixture": None, "max_frac": 0.0})
+            t["elements"] += n
+            t["failing_pure_1e-5"] += frac * n
+            t["max_frac"] = max(t["max_frac"], frac)
+            if worst > t["worst_mixed_ratio"]:
+                t["worst_mixed_ratio"], t["worst_fixture"] = worst, fx
+        for t in by.values():
+            t["fraction_failing_pure_1e-5"] = t.pop("failing_pure_1e-5") / max(1, t["elements"])
+        rec = {"bound_asserted": "|got - ref| <= 1e-5 |ref| + 1e-6 max|ref| for EVERY element (worst_mixed_ratio <= 1)",
+               "pure_form": "|got - ref| <= 1e-5 |ref| per element: the fraction of elements that miss it is recorded, not asserted",
+               "per_tensor": by, "per_fixture": [dict(fixture=f, tensor=t, worst_mixed_ratio=w, fraction_failing_pure=fr, elements=n)
+                                                  for f, t, w, fr, n in ELEMENTWISE_LOG]}
+        json.dump(rec, open(os.path.join(out, "elementwise_parity.json"), "w"), indent=1)
+    except OSError:
+        pass
+
+
 @pytest.fixture(scope="session")
 def pkg():
     return package()

@@ -342,6 +342,52 @@ def test_full_covariance_apply_ignores_garbage_in_the_pad_columns():
     eng.close()
 
 
+@pytest.mark.parametrize("garbage", [float("nan"), float("inf"), 1e30])
+def test_failed_frame_does_not_reach_the_other_frames_of_the_full_covariance_route(garbage):
+    """the fp16-split filter GEMM scales its right-hand sides by a power of two taken from their largest magnitude.  A
+    frame that fails (bad descriptor / slot never set) writes nothing else -- so whatever an uninitialised `h_ls_pilots` held in its rows
+    (NaN, Inf, 1e30) would have set the scale of every frame.  The frame kernel now writes a failed frame's rows as zeros, the scale
+    ignores non-finite values and is taken per 128-row tile: the other frames' results equal a clean batch bit for bit."""
+    geom = E.Geometry(fft_size=1024, cp_length=72, num_symbols=14, useful_subcarriers=72, num_tx=4, num_rx=4)
+    eng = E.Engine(geom, 0)
+    rs = np.random.RandomState(78)
+    P = 99
+    pil = np.sort(rs.permutation(geom.grid)[:P])
+    slot = eng.pattern_slot(pil, "linear")
+    A = rs.randn(P, P) + 1j * rs.randn(P, P)
+    W = eng.mmse_full_prepare(A @ A.conj().T / P + np.eye(P), 10.0)
+    B = 64                                                                # 256 right-hand sides: two row tiles, read in place
+    d = E.make_descs("EVA", 70.0, 10.0, slot, n=B)
+    names = ("h_ls_pilots", "frame_status")
+    clean = eng.run_frames(d, seed=5, outputs=names)
+    want = eng.mmse_full_apply_pilots(clean["h_ls_pilots"], slot, W, pads_are_zero=True)
+    bad = d.copy()
+    bad["channel_type"][7] = 9                                            # unknown profile (flagged by the taps kernel)
+    bad["pattern_slot"][40] = 3000                                        # slot never set (flagged by the frame kernel)
+    out = {"h_ls_pilots": torch.full_like(clean["h_ls_pilots"], garbage), "frame_status": torch.zeros_like(clean["frame_status"])}
+    eng.run_frames(bad, seed=5, outputs=names, out=out, check=False)
+    with pytest.raises(N_.ChestError):
+        eng.check_status()
+    st = out["frame_status"].cpu().numpy()
+    assert np.flatnonzero(st).tolist() == [7, 40]
+    assert float(out["h_ls_pilots"][[7, 40]].abs().max()) == 0.0          # the failed frames' rows: zeros, not the pre-fill
+    got = eng.mmse_full_apply_pilots(out["h_ls_pilots"], slot, W, pads_are_zero=True)
+    ok = torch.from_numpy(st == 0)
+    assert torch.isfinite(torch.view_as_real(got)).all()
+    assert torch.equal(got[ok], want[ok])
+    assert float(got[~ok].abs().max()) == 0.0
+    # a caller's own tensor with an absurd row: the damage stays inside that row's 128-row tile (frames 0..31), and a non-finite
+    # value does not enter the scale at all
+    h = clean["h_ls_pilots"].clone()
+    h[3, 1, 5] = garbage
+    got2 = eng.mmse_full_apply_pilots(h, slot, W, pads_are_zero=True)
+    assert torch.equal(got2[32:], want[32:])
+    if not np.isfinite(garbage):
+        keep = torch.ones(B, dtype=torch.bool); keep[3] = False
+        assert torch.equal(got2[keep], want[keep])
+    eng.close()
+
+
 def test_full_covariance_filter_on_the_fp16_pipe_is_float32_accurate():
     """Round 4: W h runs on v_mfma_f32_32x32x16_f16 with every f32 operand split in two fp16 terms (three products per real
     product, float32 accumulation; csrc/mmse_full.hip cgemm_w_kernel_h2, tools/fp16_split_model.py).  Against float64 NumPy it must

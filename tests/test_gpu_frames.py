@@ -1,15 +1,16 @@
 """GPU parity: the fused HIP frame pipeline (through the C ABI) against the golden fixtures generated
 from the reference, and against the float64 oracle on the engine's own Philox draws.
 
-Tolerance (BASELINE.json north_star): <= 1e-5 relative on complex-float channel estimates; relative
-error here is max|got - ref| / max|ref| per tensor.  Pilot indices / masks are bit-exact.
+Tolerance (BASELINE.json north_star): <= 1e-5 relative on complex-float channel estimates.  Two forms are asserted:
+per tensor, max|got - ref| / max|ref| <= 1e-5; and per ELEMENT, |got - ref| <= 1e-5 |ref| + 1e-6 max|ref| (the golden test;
+the fraction of elements missing the pure per-element form is recorded).  Pilot indices / masks are bit-exact.
 """
 import importlib
 
 import numpy as np
 import pytest
 
-from conftest import case_config, case_draws, golden_names, load_golden, relerr
+from conftest import ELEMENTWISE_LOG, case_config, case_draws, elementwise, golden_names, load_golden, relerr
 from oracle import cpu_ref as O
 from oracle import philox as PH
 
@@ -55,6 +56,13 @@ def test_frame_pipeline_matches_reference_golden(name):
     for t in range(T):                                                               # quirk Q9
         assert relerr(H_ls[:, :, t, :], g["H_ls"]) < TOL
         assert relerr(H_mm[:, :, t, :], g["H_mmse"]) < TOL
+    # element-wise: every element of H / rx / H_ls / H_mmse within 1e-5 of ITS OWN magnitude plus 1e-6 of the
+    # tensor's scale; the fraction of elements that miss the pure per-element form goes to gpurun_out/elementwise_parity.json
+    for tname, got, ref in (("H", out["H"][0].cpu().numpy(), g["H"]), ("rx", out["rx"][0].cpu().numpy(), g["rx"]),
+                            ("H_ls", H_ls[:, :, 0, :], g["H_ls"]), ("H_mmse", H_mm[:, :, 0, :], g["H_mmse"])):
+        worst, frac, nel = elementwise(got, ref)
+        ELEMENTWISE_LOG.append((name, tname, worst, frac, nel))
+        assert worst <= 1.0, (name, tname, worst, frac)
     m = out["metrics"][0].cpu().numpy().astype(np.float64)
     n = m[6]
     mse_ls = m[1] / n

@@ -35,14 +35,48 @@ def test_one_rank_rccl_runs_the_packages_collectives_on_device_tensors():
     assert rec["gather_equal"] and rec["all_gather_equal"] and rec["broadcast_equal"] and rec["bench_gather_equal"]
 
 
-@pytest.mark.parametrize("workload,frames", [("cfg2_2x2_eva_ls_mmse", 512), ("cfg5_4x4_2048_fullcov", 64)])
-def test_bench_rehearses_its_collectives_through_one_rank_rccl(workload, frames):
-    """bench.py --rccl-rehearsal: the measured job with its N > 1 control flow switched on at N = 1 (process group, barrier,
-    gather of the metric sums, MAX-reduction of the time; config 5 also broadcasts the prepared filter W)."""
+def _check_multi_rank_fields(rec, world):
+    """What VERDICT r4 asked the N > 1 line to carry: the end-of-job gather timed on its own (warmed before t0), every rank's own
+    step / frame-kernel time beside the MAX that `value` uses, and -- unless switched off -- the CPU path of the same run."""
+    assert rec["collective_ms"] > 0 and rec["collective"]["warmed_before_timed_region"]
+    assert rec["collective"]["value_with_collective"] <= rec["value"] * (1 + 1e-9)
+    pr = rec["per_rank"]
+    for key in ("ms_per_step", "frame_kernel_ms", "stream_ms_per_step"):
+        st = pr[key]
+        assert len(st["all"]) == world and st["min"] <= st["median"] <= st["max"] and 0 <= st["argmax"] < world
+        assert st["max"] == max(st["all"]) and st["min"] > 0
+    # the barrier-to-barrier time of the slowest rank bounds every rank's own time from above
+    assert pr["ms_per_step"]["max"] <= rec["ms_per_step"] * 1.001 + 0.01
+
+
+@pytest.mark.parametrize("workload,frames,cpu", [("cfg2_2x2_eva_ls_mmse", 512, True), ("cfg5_4x4_2048_fullcov", 64, False)])
+def test_bench_rehearses_its_collectives_through_one_rank_rccl(workload, frames, cpu):
+    """bench.py --rccl-rehearsal: the measured job with its N > 1 control flow switched on at N = 1 (process group, warmed gather /
+    all-gather / MAX-reduction, barrier, the timed end-of-job gather; config 5 also broadcasts the prepared filter W)."""
+    extra = ["--cpu-budget-s", "1"] if cpu else ["--no-cpu-baseline"]
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--rccl-rehearsal", "--workload", workload, "--frames", str(frames),
-                        "--steps", "2", "--warmup", "1", "--no-cpu-baseline"], env=_env(), capture_output=True, text=True, timeout=900)
+                        "--steps", "2", "--warmup", "1"] + extra, env=_env(), capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stderr[-3000:]
     assert len(p.stdout.strip().splitlines()) == 1, p.stdout[:2000]      # RCCL's version banner and the like must not reach stdout
     rec = _json_line(p.stdout)
     assert rec["n_gpus"] == 1 and rec["config"]["collectives"] == "executed (nccl, world 1)"
     assert rec["value"] > 0 and rec["est_mse"]["mmse"] > 0
+    _check_multi_rank_fields(rec, 1)
+    if cpu:
+        cb = rec["cpu_baseline"]
+        assert cb["value"] > 0 and cb["cores"] >= 1 and cb["kind"] == "port" and cb["cpu_model"] and cb["host"]["os_cpu_count"] >= cb["cores"]
+    else:
+        assert "cpu_baseline" not in rec
+
+
+def test_two_gloo_ranks_sharing_the_gpu_rehearse_the_n_gt_1_line():
+    """The N = 2 control flow end to end (self-spawned ranks, contiguous frame ranges, gather to rank 0, MAX over ranks), two gloo
+    ranks on the one GPU: the line carries both ranks' own times, the collective's time and the CPU baseline at N > 1."""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--frames", "512",
+                        "--steps", "3", "--warmup", "1", "--cpu-budget-s", "1"], env=_env(), capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    rec = _json_line(p.stdout)
+    assert rec["n_gpus"] == 2 and rec["config"]["collectives"] == "executed (gloo, world 2)"
+    assert rec["value"] > 0 and rec["config"]["frames_per_step_per_gpu"] == 512
+    _check_multi_rank_fields(rec, 2)
+    assert rec["cpu_baseline"]["value"] > 0
