@@ -14,7 +14,7 @@ MAX_PATHS = 16
 NUM_OSC = 20
 NUM_METRICS = 8
 M_SUM_H2, M_SUM_ERR_LS, M_SUM_ERR_MMSE, M_SIGNAL_POWER, M_NOISE_STD, M_ALPHA0, M_COUNT = range(7)
-ABI_VERSION = 2
+ABI_VERSION = 3
 FRAME_OK, FRAME_BAD_DESC, FRAME_NO_PLAN = 0, 1, 2
 KERNEL_IDS = {"taps_kernel": 0, "frame_kernel": 1, "pack_kernels": 2, "cgemm_w_kernel": 3, "interp_from_pilots_kernel": 4,
               "plan_kernels": 5}
@@ -52,6 +52,8 @@ class FrameOutputs(C.Structure):
 _vp, _i32, _i64, _u64, _f = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_float
 SIGNATURES = {
     "chest_create": (_i32, [C.POINTER(Config), C.POINTER(_vp)]),
+    "chest_create_grid": (_i32, [_i32, _i32, _i32, _i32, _i32, C.POINTER(_vp)]),
+    "chest_set_profile": (_i32, [_vp, _i32, _i32, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "chest_destroy": (None, [_vp]),
     "chest_last_error": (C.c_char_p, []),
     "chest_abi_version": (_i32, []),

@@ -28,8 +28,10 @@ def _engine_for(shape):
     """Engine whose grid matches a (S, R, T, nsc) estimate shape.  Estimation does not depend on
     fft_size / cp / spacing, so those take the defaults."""
     S, R, T, nsc = (int(v) for v in shape)
-    if nsc % 2 == 0:
-        raise NotImplementedError("the engine handles DC-removed grids (odd subcarrier counts) only")
+    if nsc % 2 == 0 or nsc < 3:
+        # no (fft_size, useful_subcarriers) pair has this many DC-removed bins: an explicit grid (chest_create_grid) -- the reference's
+        # estimators take any (S, nsc) (src/baseline_estimators.py:83-117)
+        return _engine.get_engine(_engine.Geometry.grid_only(S, nsc, T, R))
     fft = 1024
     while fft < nsc + 1:
         fft *= 2

@@ -45,6 +45,14 @@ class MIMOConfig:
     num_rx: int = 2
 
 
+# the three tables the library carries itself (chest_abi.hip kProfiles = reference :41-54), for telling an edited class dict apart
+_BUILTIN_PROFILES = {
+    'EPA': (np.array([0, 30, 70, 90, 110, 190, 410]) * 1e-9, np.array([0.0, -1.0, -2.0, -3.0, -8.0, -17.2, -20.8])),
+    'EVA': (np.array([0, 30, 150, 310, 370, 710, 1090, 1730, 2510]) * 1e-9, np.array([0.0, -1.5, -1.4, -3.6, -0.6, -9.1, -7.0, -12.0, -16.9])),
+    'ETU': (np.array([0, 50, 120, 200, 230, 500, 1600, 2300, 5000]) * 1e-9, np.array([-1.0, -1.0, -1.0, 0.0, 0.0, 0.0, -3.0, -5.0, -7.0])),
+}
+
+
 def _geometry(ofdm: OFDMConfig, num_tx: int, num_rx: int, num_symbols=None) -> _engine.Geometry:
     return _engine.Geometry(fft_size=int(ofdm.fft_size), cp_length=int(ofdm.cp_length),
                             num_symbols=int(ofdm.num_symbols if num_symbols is None else num_symbols),
@@ -81,6 +89,25 @@ class ChannelModel:
         self.powers_linear = p / np.sum(p)
         self.delay_samples = np.round(self.delays * sampling_rate).astype(int)
         self.num_paths = len(self.delays)
+        # The class dict is the reference's extension point (read here, at construction, like :72): an EDITED entry or a NEW name
+        # is uploaded as a custom tap table (chest_set_profile) into an engine of its own, keyed by the table's content; the three
+        # built-in tables take the library's own copies.
+        builtin = _BUILTIN_PROFILES.get(self.model_type)
+        d = np.asarray(self.delays, dtype=np.float64).reshape(-1)
+        q = np.asarray(self.powers_db, dtype=np.float64).reshape(-1)
+        if builtin is not None and np.array_equal(d, builtin[0]) and np.array_equal(q, builtin[1]):
+            self._code, self._profile_tag = _engine.channel_code(self.model_type), ""
+        else:
+            import hashlib
+            self._code = _engine.N.CHANNEL_CODES.get(self.model_type, 0)
+            self._profile_tag = "profile:" + hashlib.blake2b(d.tobytes() + q.tobytes() + bytes([self._code]), digest_size=8).hexdigest()
+
+    def _engine_with_profile(self, geometry):
+        """Engine for ``geometry`` that carries this model's tap table (the shared engine for the built-in tables)."""
+        eng = _engine.get_engine(geometry, tag=self._profile_tag)
+        if self._profile_tag and self._code not in eng._profiles:
+            eng.set_profile(self._code, self.delays, self.powers_db)
+        return eng
 
     def _draw_oscillators(self, num_tx: int, num_rx: int):
         """20 angles then 20 phases per (path, tx, rx), in that loop order (:102-110)."""
@@ -95,18 +122,17 @@ class ChannelModel:
 
     def _engine_for_rate(self, num_tx, num_rx):
         # the dense kernel only needs sampling_rate = fft_size * spacing; any geometry with that product works
-        return _engine.get_engine(_engine.Geometry(fft_size=1024, cp_length=72, num_symbols=14, useful_subcarriers=600,
-                                                   subcarrier_spacing=float(self.sampling_rate) / 1024.0,
-                                                   num_tx=max(1, min(int(num_tx), 8)), num_rx=max(1, min(int(num_rx), 8))))
+        return self._engine_with_profile(_engine.Geometry(fft_size=1024, cp_length=72, num_symbols=14, useful_subcarriers=600,
+                                             subcarrier_spacing=float(self.sampling_rate) / 1024.0,
+                                             num_tx=max(1, min(int(num_tx), 8)), num_rx=max(1, min(int(num_rx), 8))))
 
     def generate_time_varying_channel(self, num_samples: int, num_tx: int, num_rx: int) -> np.ndarray:
         """(num_samples, num_rx, num_tx, max_delay+1) complex Jakes channel (:84-127)."""
         ua, up = self._draw_oscillators(num_tx, num_rx)
         eng = self._engine_for_rate(num_tx, num_rx)
-        _, d = eng.tap_table(self.model_type)
-        if not np.array_equal(d, self.delay_samples):
-            raise NotImplementedError("custom CHANNEL_PROFILES entries are not supported by the engine")
-        h = eng.time_varying_channel(self.model_type, self.doppler_hz, num_samples, num_tx, num_rx, ua, up)
+        _, d = eng.tap_table(self._code)
+        assert np.array_equal(d, self.delay_samples), "the engine's tap table and ChannelModel.delay_samples disagree"
+        h = eng.time_varying_channel(self._code, self.doppler_hz, num_samples, num_tx, num_rx, ua, up)
         return _np128(h)
 
 
@@ -172,7 +198,7 @@ class MIMOChannel:
         self.ofdm_system = OFDMSystem(ofdm_config)
 
     def _eng(self, num_symbols):
-        return _engine.get_engine(_geometry(self.ofdm_config, self.mimo_config.num_tx, self.mimo_config.num_rx, num_symbols))
+        return self.channel_model._engine_with_profile(_geometry(self.ofdm_config, self.mimo_config.num_tx, self.mimo_config.num_rx, num_symbols))
 
     def _check_rate(self):
         fs = self.ofdm_config.fft_size * self.ofdm_config.subcarrier_spacing
@@ -187,22 +213,17 @@ class MIMOChannel:
         eng = self._eng(num_symbols)
         g = eng.geom
         slot = eng.pattern_slot(np.arange(min(4, g.grid)), None, with_plan=False)     # any pattern: H ignores it
-        d = _engine.make_descs(cm.model_type, cm.doppler_hz, 0.0, slot, n=1)
+        d = _engine.make_descs(cm._code, cm.doppler_hz, 0.0, slot, n=1)
         out = eng.run_frames(d, injected={"u_angle": ua[None], "u_phase": up[None]}, outputs=("H",))
         return _np128(out["H"][0])
 
     def apply_channel(self, transmitted_symbols: np.ndarray, channel_response: np.ndarray, snr_db: float) -> np.ndarray:
         """y = Hx per RE plus AWGN scaled from the realised frame power (:313-345)."""
         num_symbols, num_rx, num_tx, num_sc = channel_response.shape
-        if num_sc % 2 == 0:
-            raise NotImplementedError("the engine handles DC-removed grids (odd subcarrier counts) only")
         n_re = np.random.randn(num_symbols, num_rx, num_sc)
         n_im = np.random.randn(num_symbols, num_rx, num_sc)
-        geom = _engine.Geometry(fft_size=int(self.ofdm_config.fft_size), cp_length=int(self.ofdm_config.cp_length),
-                                num_symbols=int(num_symbols), useful_subcarriers=int(num_sc) + 1,
-                                subcarrier_spacing=float(self.ofdm_config.subcarrier_spacing), num_tx=int(num_tx),
-                                num_rx=int(num_rx))
-        eng = _engine.get_engine(geom)
+        # y = Hx + n reads array shapes only (:330-342): any grid, an even subcarrier count included
+        eng = _engine.get_engine(_engine.Geometry.grid_only(num_symbols, num_sc, num_tx, num_rx))
         rx = eng.apply_channel(np.asarray(transmitted_symbols), np.asarray(channel_response), snr_db, n_re[None], n_im[None])
         return _np128(rx[0])
 
@@ -221,8 +242,8 @@ def time_domain_link(ofdm_config: OFDMConfig, channel_model: ChannelModel, tx_gr
     time_tx = eng.ofdm_modulate(tx_grids.reshape(T * S, nsc)).reshape(T, S * spl)
     ua, up = channel_model._draw_oscillators(T, num_rx)
     ceng = channel_model._engine_for_rate(T, num_rx)
-    h = ceng.time_varying_channel(channel_model.model_type, channel_model.doppler_hz, S * spl, T, num_rx, ua, up)
-    y = ceng.tdl_apply(time_tx, h, channel_model.model_type)
+    h = ceng.time_varying_channel(channel_model._code, channel_model.doppler_hz, S * spl, T, num_rx, ua, up)
+    y = ceng.tdl_apply(time_tx, h, channel_model._code)
     rx = eng.ofdm_demodulate(y.reshape(num_rx * S, spl)).reshape(num_rx, S, nsc)
     return {'rx_grids': _np128(rx), 'time_tx': _np128(time_tx), 'time_rx': _np128(y), 'h': h, 'u_angle': ua, 'u_phase': up}
 
@@ -253,9 +274,9 @@ def simulate_transmission(config: Dict, channel_type: str = 'EPA', doppler_hz: f
     n_re = np.random.randn(S, R, num_sc)                                             # draw 5 (:342)
     n_im = np.random.randn(S, R, num_sc)
 
-    eng = _engine.get_engine(_geometry(ofdm_cfg, T, R))
+    eng = channel_model._engine_with_profile(_geometry(ofdm_cfg, T, R))
     slot = eng.pattern_slot(pilot_pattern.pilot_indices, None, with_plan=False)
-    descs = _engine.make_descs(channel_model.model_type, doppler_hz, snr_db, slot, n=1)
+    descs = _engine.make_descs(channel_model._code, doppler_hz, snr_db, slot, n=1)
     out = eng.run_frames(descs, injected={"u_sym": np.concatenate([u_pilot, u_data])[None], "u_angle": ua[None],
                                           "u_phase": up[None], "n_re": n_re[None], "n_im": n_im[None]},
                          outputs=("tx", "rx", "H", "pilot_symbols"))

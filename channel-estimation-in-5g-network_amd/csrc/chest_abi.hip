@@ -30,6 +30,65 @@ static const ProfileTable kProfiles[CHEST_NUM_PROFILES] = {
     {9, {0, 50, 120, 200, 230, 500, 1600, 2300, 5000}, {-1.0, -1.0, -1.0, 0.0, 0.0, 0.0, -3.0, -5.0, -7.0}},
 };
 
+// Tap table of ONE channel_type code from (delay in seconds, relative power in dB) per path, exactly the arithmetic of
+// ChannelModel.__init__ (src/channel_simulator.py:72-82): the frame-kernel form (distinct delays after the overwrite quirk, twiddle
+// steps) and the Gram matrix of its tap twiddles over the used bins.
+static int build_profile(chest_ctx* ctx, int ty, int n, const double* delays_s, const double* powers_db) {
+    const chest_config& c = ctx->cfg;
+    FrameParams& fp = ctx->fp;
+    if (n < 1 || n > CHEST_MAX_PATHS) { set_error("a delay profile has 1..%d paths (got %d)", CHEST_MAX_PATHS, n); return CHEST_EINVAL; }
+    const double fs = (double)c.fft_size * c.subcarrier_spacing;          // (:136, :379)
+    double lin[CHEST_MAX_PATHS], tot = 0.0;
+    int32_t dsamp[CHEST_MAX_PATHS];
+    for (int l = 0; l < n; ++l) {
+        lin[l] = pow(10.0, powers_db[l] / 10.0); tot += lin[l];                                       // (:75)
+        // np.round(delays * fs).astype(int): round-half-even on float64 (:81)
+        const double d = nearbyint(delays_s[l] * fs);
+        if (!(d >= 0.0) || d > 1.0e6 || !(lin[l] >= 0.0) || !isfinite(lin[l])) { set_error("profile %d: path %d has delay %g s / power %g dB", ty, l, delays_s[l], powers_db[l]); return CHEST_EINVAL; }
+        dsamp[l] = (int32_t)d;
+    }
+    if (!(tot > 0.0)) { set_error("profile %d: the path powers sum to 0", ty); return CHEST_EINVAL; }
+    TapProfile tp;
+    memset(&tp, 0, sizeof(tp));
+    tp.npaths = n;
+    for (int l = 0; l < n; ++l) {
+        // later path with the same delay overwrites the earlier one (:125, quirk Q1)
+        bool overwritten = false;
+        for (int m = l + 1; m < n; ++m)
+            if (dsamp[m] == dsamp[l]) overwritten = true;
+        if (dsamp[l] > tp.max_delay) tp.max_delay = dsamp[l];
+        if (overwritten) continue;
+        if (tp.ntaps >= KT) { set_error("profile %d has more than %d distinct delays", ty, KT); return CHEST_EINVAL; }
+        tp.delay[tp.ntaps] = dsamp[l];
+        tp.path[tp.ntaps] = l;
+        tp.amp[tp.ntaps] = (float)(sqrt(lin[l] / tot) / sqrt(2.0 * CHEST_NUM_OSC));                   // (:78, :104, :124)
+        const double sa = -2.0 * M_PI * (double)dsamp[l] / (double)fp.N;
+        tp.step[tp.ntaps][0] = (float)cos(sa); tp.step[tp.ntaps][1] = (float)sin(sa);
+        ++tp.ntaps;
+    }
+    // accepted: commit
+    ctx->num_paths[ty] = n;
+    for (int l = 0; l < CHEST_MAX_PATHS; ++l) {
+        ctx->powers_linear[ty][l] = l < n ? lin[l] / tot : 0.0;
+        ctx->delay_samples[ty][l] = l < n ? dsamp[l] : 0;
+    }
+    fp.prof[ty] = tp;
+    // Gram matrix Q[d][d'] = sum_k W_d[k] conj(W_d'[k]), W_d[k] = exp(-2 pi j kappa_k delay_d / N), float64 on the
+    // host: sum_k |sum_d a_d W_d[k]|^2 = sum_{d,d'} a_d conj(a_d') Q[d][d'] gives frame powers without a grid pass.
+    for (int d1 = 0; d1 < KT; ++d1)
+        for (int d2 = 0; d2 < KT; ++d2) {
+            double re = 0.0, im = 0.0;
+            if (d1 < tp.ntaps && d2 < tp.ntaps)
+                for (int k = 0; k < fp.nsc; ++k) {
+                    const int kappa = (k < fp.half) ? (k - fp.half) : (k - fp.half + 1);
+                    const double a = -2.0 * M_PI * (double)kappa * (double)(tp.delay[d1] - tp.delay[d2]) / (double)fp.N;
+                    re += cos(a); im += sin(a);
+                }
+            ctx->gram_host[((size_t)ty * KT + d1) * KT + d2] = make_float2((float)re, (float)im);
+        }
+    return CHEST_OK;
+}
+
 static int build_tables(chest_ctx* ctx) {
     const chest_config& c = ctx->cfg;
     FrameParams& fp = ctx->fp;
@@ -41,49 +100,13 @@ static int build_tables(chest_ctx* ctx) {
     fp.T = c.num_tx; fp.R = c.num_rx; fp.G = fp.S * fp.nsc;
     const double fs = (double)c.fft_size * c.subcarrier_spacing;          // (:136, :379)
     for (int s = 0; s < fp.S; ++s) fp.ts[s] = (float)((double)((int64_t)s * (c.fft_size + c.cp_length)) / fs);
-    for (int ty = 0; ty < CHEST_NUM_PROFILES; ++ty) {
-        const ProfileTable& pt = kProfiles[ty];
-        double lin[CHEST_MAX_PATHS], tot = 0.0;
-        for (int l = 0; l < pt.n; ++l) { lin[l] = pow(10.0, pt.power_db[l] / 10.0); tot += lin[l]; }   // (:75)
-        ctx->num_paths[ty] = pt.n;
-        for (int l = 0; l < pt.n; ++l) {
-            ctx->powers_linear[ty][l] = lin[l] / tot;                                                 // (:78)
-            // np.round(delays * fs).astype(int): round-half-even on float64 (:81)
-            ctx->delay_samples[ty][l] = (int32_t)nearbyint((pt.delay_ns[l] * 1e-9) * fs);
-        }
-        TapProfile& tp = fp.prof[ty];
-        tp.ntaps = 0; tp.npaths = pt.n; tp.max_delay = 0;
-        for (int l = 0; l < pt.n; ++l) {
-            // later path with the same delay overwrites the earlier one (:125, quirk Q1)
-            bool overwritten = false;
-            for (int m = l + 1; m < pt.n; ++m)
-                if (ctx->delay_samples[ty][m] == ctx->delay_samples[ty][l]) overwritten = true;
-            if (ctx->delay_samples[ty][l] > tp.max_delay) tp.max_delay = ctx->delay_samples[ty][l];
-            if (overwritten) continue;
-            if (tp.ntaps >= KT) { set_error("profile %d has more than %d distinct delays", ty, KT); return CHEST_EINVAL; }
-            tp.delay[tp.ntaps] = ctx->delay_samples[ty][l];
-            tp.path[tp.ntaps] = l;
-            tp.amp[tp.ntaps] = (float)(sqrt(ctx->powers_linear[ty][l]) / sqrt(2.0 * CHEST_NUM_OSC));   // (:104, :124)
-            const double sa = -2.0 * M_PI * (double)ctx->delay_samples[ty][l] / (double)fp.N;
-            tp.step[tp.ntaps][0] = (float)cos(sa); tp.step[tp.ntaps][1] = (float)sin(sa);
-            ++tp.ntaps;
-        }
-    }
-    // Gram matrices Q[d][d'] = sum_k W_d[k] conj(W_d'[k]), W_d[k] = exp(-2 pi j kappa_k delay_d / N), float64 on the
-    // host: sum_k |sum_d a_d W_d[k]|^2 = sum_{d,d'} a_d conj(a_d') Q[d][d'] gives frame powers without a grid pass.
     ctx->gram_host.assign((size_t)CHEST_NUM_PROFILES * KT * KT, make_float2(0.f, 0.f));
     for (int ty = 0; ty < CHEST_NUM_PROFILES; ++ty) {
-        const TapProfile& tp = fp.prof[ty];
-        for (int d1 = 0; d1 < tp.ntaps; ++d1)
-            for (int d2 = 0; d2 < tp.ntaps; ++d2) {
-                double re = 0.0, im = 0.0;
-                for (int k = 0; k < fp.nsc; ++k) {
-                    const int kappa = (k < fp.half) ? (k - fp.half) : (k - fp.half + 1);
-                    const double a = -2.0 * M_PI * (double)kappa * (double)(tp.delay[d1] - tp.delay[d2]) / (double)fp.N;
-                    re += cos(a); im += sin(a);
-                }
-                ctx->gram_host[((size_t)ty * KT + d1) * KT + d2] = make_float2((float)re, (float)im);
-            }
+        const ProfileTable& pt = kProfiles[ty];
+        double ds[9];
+        for (int l = 0; l < pt.n; ++l) ds[l] = pt.delay_ns[l] * 1e-9;     // np.array([...]) * 1e-9 (:42-53)
+        const int rc = build_profile(ctx, ty, pt.n, ds, pt.power_db);
+        if (rc != CHEST_OK) return rc;
     }
     return CHEST_OK;
 }
@@ -177,6 +200,50 @@ int chest_create(const chest_config* cfg, chest_ctx** out) {
     return CHEST_OK;
 }
 
+int chest_create_grid(int32_t num_symbols, int32_t num_subcarriers, int32_t num_tx, int32_t num_rx, int32_t device, chest_ctx** out) {
+    if (out == nullptr) { set_error("chest_create_grid: null argument"); return CHEST_EINVAL; }
+    *out = nullptr;
+    if (num_symbols < 1 || num_symbols > CHEST_MAX_SYMBOLS || num_subcarriers < 1 || num_tx < 1 || num_tx > 8 || num_rx < 1 || num_rx > 8 ||
+        (int64_t)num_symbols * num_subcarriers > 65535) {
+        set_error("chest_create_grid: unsupported grid (S %d nsc %d T %d R %d; S <= %d, S*nsc <= 65535, 1..8 antennas)", num_symbols,
+                  num_subcarriers, num_tx, num_rx, CHEST_MAX_SYMBOLS);
+        return CHEST_EINVAL;
+    }
+    int ndev = 0;
+    CHEST_HIP(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) { set_error("chest_create_grid: device %d of %d", device, ndev); return CHEST_EINVAL; }
+    chest::DeviceGuard guard_(device);
+    if (!guard_.ok) { set_error("hipSetDevice(%d) failed", device); return CHEST_EHIP; }
+    chest_ctx* ctx = new (std::nothrow) chest_ctx();
+    if (!ctx) { set_error("out of host memory"); return CHEST_ENOMEM; }
+    memset(&ctx->cfg, 0, sizeof(ctx->cfg));                      // fft_size == 0 marks the context as grid-only
+    ctx->cfg.num_symbols = num_symbols; ctx->cfg.num_tx = num_tx; ctx->cfg.num_rx = num_rx; ctx->cfg.device = device;
+    FrameParams& fp = ctx->fp;
+    memset(&fp, 0, sizeof(fp));
+    fp.S = num_symbols; fp.nsc = num_subcarriers; fp.T = num_tx; fp.R = num_rx; fp.G = num_symbols * num_subcarriers;
+    if (hipMalloc((void**)&ctx->d_status, sizeof(int32_t)) != hipSuccess || hipMemset(ctx->d_status, 0, sizeof(int32_t)) != hipSuccess ||
+        hipMalloc((void**)&ctx->d_fp, sizeof(FrameParams)) != hipSuccess ||
+        hipMemcpy(ctx->d_fp, &ctx->fp, sizeof(FrameParams), hipMemcpyHostToDevice) != hipSuccess) {
+        set_error("chest_create_grid: device allocation failed");
+        chest_destroy(ctx);
+        return CHEST_EHIP;
+    }
+    *out = ctx;
+    return CHEST_OK;
+}
+
+int chest_set_profile(chest_ctx* ctx, int32_t type, int32_t num_paths, const double* delays_s, const double* powers_db) {
+    if (!ctx || !delays_s || !powers_db || (unsigned)type >= CHEST_NUM_PROFILES) { set_error("chest_set_profile: bad argument (channel_type 0..%d)", CHEST_NUM_PROFILES - 1); return CHEST_EINVAL; }
+    if (ctx->cfg.fft_size == 0) { set_error("chest_set_profile: a grid-only context (chest_create_grid) has no channel model"); return CHEST_ESTATE; }
+    CHEST_GUARD(ctx);
+    CHEST_HIP(hipDeviceSynchronize());                           // launches in flight read the tables being replaced
+    const int rc = build_profile(ctx, type, num_paths, delays_s, powers_db);
+    if (rc != CHEST_OK) return rc;
+    CHEST_HIP(hipMemcpy(ctx->d_fp, &ctx->fp, sizeof(FrameParams), hipMemcpyHostToDevice));
+    CHEST_HIP(hipMemcpy(ctx->d_gram, ctx->gram_host.data(), ctx->gram_host.size() * sizeof(float2), hipMemcpyHostToDevice));
+    return CHEST_OK;
+}
+
 void chest_destroy(chest_ctx* ctx) {
     if (!ctx) return;
     chest::DeviceGuard guard_(ctx->cfg.device);
@@ -193,10 +260,14 @@ void chest_destroy(chest_ctx* ctx) {
     delete ctx;
 }
 
+#define CHEST_NEEDS_OFDM(ctx, who)                                                                                          \
+    if ((ctx)->cfg.fft_size == 0) { set_error("%s: a grid-only context (chest_create_grid) has no OFDM numerology / channel model", who); return CHEST_ESTATE; }
+
 int chest_get_used_indices(chest_ctx* ctx, int32_t* num_sc, int64_t* out) {
     if (!ctx) { set_error("null context"); return CHEST_EINVAL; }
     if (num_sc) *num_sc = ctx->fp.nsc;
     if (out) {
+        CHEST_NEEDS_OFDM(ctx, "chest_get_used_indices");
         const int dc = ctx->fp.N / 2, half = ctx->fp.half;
         int n = 0;
         for (int i = dc - half; i < dc + half; ++i)
@@ -207,6 +278,7 @@ int chest_get_used_indices(chest_ctx* ctx, int32_t* num_sc, int64_t* out) {
 
 int chest_get_tap_table(chest_ctx* ctx, int32_t type, int32_t* num_paths, int32_t* delay_samples, double* powers_linear) {
     if (!ctx || (unsigned)type >= CHEST_NUM_PROFILES) { set_error("unknown channel_type %d", type); return CHEST_EINVAL; }
+    CHEST_NEEDS_OFDM(ctx, "chest_get_tap_table");
     if (num_paths) *num_paths = ctx->num_paths[type];
     for (int l = 0; l < ctx->num_paths[type]; ++l) {
         if (delay_samples) delay_samples[l] = ctx->delay_samples[type][l];
@@ -446,6 +518,7 @@ int chest_frames_run(chest_ctx* ctx, void* stream, int32_t B, const chest_frame_
                      void* workspace, int64_t workspace_bytes) {
     if (!ctx || !out || (B > 0 && !descs)) { set_error("chest_frames_run: null argument"); return CHEST_EINVAL; }
     if (B < 0) { set_error("chest_frames_run: negative frame count"); return CHEST_EINVAL; }
+    CHEST_NEEDS_OFDM(ctx, "chest_frames_run");
     if (ctx->patterns.empty()) { set_error("chest_frames_run: no pilot pattern uploaded"); return CHEST_ESTATE; }
     if (out->pilot_symbols != nullptr) {
         int Pmax = 0;
@@ -492,18 +565,21 @@ int chest_apply_channel(chest_ctx* ctx, void* stream, int32_t B, const float* tx
 int chest_time_varying_channel(chest_ctx* ctx, void* stream, int32_t type, float fd, int64_t ns, int32_t T, int32_t R,
                                const float* ua, const float* up, uint64_t seed, uint64_t frame, float* out) {
     if (!ctx || ns < 0 || T < 0 || R < 0 || (ns > 0 && !out)) { set_error("chest_time_varying_channel: bad argument"); return CHEST_EINVAL; }
+    CHEST_NEEDS_OFDM(ctx, "chest_time_varying_channel");
     CHEST_GUARD(ctx);
     return launch_tv_channel(ctx, (hipStream_t)stream, type, fd, ns, T, R, ua, up, seed, frame, out);
 }
 
 int chest_ofdm_modulate(chest_ctx* ctx, void* stream, int32_t n, const float* sym, float* out) {
     if (!ctx || n < 0 || (n > 0 && (!sym || !out))) { set_error("chest_ofdm_modulate: bad argument"); return CHEST_EINVAL; }
+    CHEST_NEEDS_OFDM(ctx, "chest_ofdm_modulate");
     CHEST_GUARD(ctx);
     return launch_ofdm(ctx, (hipStream_t)stream, n, sym, out, true);
 }
 
 int chest_ofdm_demodulate(chest_ctx* ctx, void* stream, int32_t n, const float* tin, float* out) {
     if (!ctx || n < 0 || (n > 0 && (!tin || !out))) { set_error("chest_ofdm_demodulate: bad argument"); return CHEST_EINVAL; }
+    CHEST_NEEDS_OFDM(ctx, "chest_ofdm_demodulate");
     CHEST_GUARD(ctx);
     return launch_ofdm(ctx, (hipStream_t)stream, n, tin, out, false);
 }
@@ -517,6 +593,7 @@ int chest_equalize(chest_ctx* ctx, void* stream, int32_t B, const float* rx, con
 int chest_tdl_apply(chest_ctx* ctx, void* stream, int32_t type, int64_t ns, int32_t T, int32_t R, const float* x, const float* h,
                     float* y) {
     if (!ctx || ns < 0 || T < 0 || R < 0 || (ns > 0 && (!x || !h || !y))) { set_error("chest_tdl_apply: bad argument"); return CHEST_EINVAL; }
+    CHEST_NEEDS_OFDM(ctx, "chest_tdl_apply");
     CHEST_GUARD(ctx);
     return launch_tdl(ctx, (hipStream_t)stream, type, ns, T, R, x, h, y);
 }

@@ -57,9 +57,9 @@ class ChannelEstimationDataset:
         ua, up = cm._draw_oscillators(T, R)
         n_re = np.random.randn(S, R, nsc)
         n_im = np.random.randn(S, R, nsc)
-        eng = _engine.get_engine(geom)
+        eng = cm._engine_with_profile(geom)
         slot = eng.pattern_slot(pattern.pilot_indices, "linear")
-        out = eng.run_frames(_engine.make_descs(cm.model_type, doppler_hz, snr_db, slot, n=1),
+        out = eng.run_frames(_engine.make_descs(cm._code, doppler_hz, snr_db, slot, n=1),
                              injected={"u_sym": np.concatenate([u_pilot, u_data])[None], "u_angle": ua[None],
                                        "u_phase": up[None], "n_re": n_re[None], "n_im": n_im[None]},
                              outputs=("tx", "rx", "H", "H_ls"))
@@ -357,9 +357,94 @@ class TrainingDataset:
         return self.inputs[idx], self.targets[idx], self.pilot_mask[idx]
 
 
+def _free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def _spawn_ranks(n: int, argv) -> int:
+    """Start ``n`` copies of this CLI, one per GPU, with the torchrun environment (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*),
+    BEFORE this process has touched the GPU (the parent only waits).  0 only if every rank exited 0; the first failure stops
+    the remaining ranks (exact PIDs)."""
+    import os
+    import subprocess
+    import sys
+    import time
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, "-c",
+                                       "import importlib, sys; sys.argv = ['dataset_generator'] + sys.argv[1:]; "
+                                       f"sys.path.insert(0, {os.path.dirname(os.path.dirname(os.path.abspath(__file__)))!r}); "
+                                       f"importlib.import_module({__name__!r}).main()"] + list(argv), env=env))
+    rc, alive = 0, set(range(n))
+    while alive:
+        for r in sorted(alive):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            alive.discard(r)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                print(f"dataset_generator: rank {r} exited with code {code}; stopping the other ranks", file=sys.stderr, flush=True)
+                for q in alive:
+                    procs[q].terminate()
+        if alive:
+            time.sleep(0.05)
+    return rc
+
+
+def merge_manifests(out_dir, split: str, world: int) -> Dict:
+    """Rank 0's last step of a sharded job: ONE manifest over every rank's chunk files, in global frame order -- the role of the
+    reference's ``_merge_chunks`` (run_phase3_robust.py:261-288), except that the tensors stay in their chunk files (1 M frames are
+    1.1 TB: they do not fit one array) and the merged file lists them.  ``load_merged(out_dir, split)`` concatenates them for
+    datasets that do fit."""
+    import json
+    import os
+    parts = [json.load(open(os.path.join(out_dir, f"{split}_rank{r:02d}_manifest.json"))) for r in range(world)]
+    chunks = sorted((dict(c, rank=p["rank"]) for p in parts for c in p["chunks"]), key=lambda c: c["first_frame"])
+    pos = parts[0]["begin"] if parts else 0
+    for c in chunks:                                                       # the shards tile [0, total) without gaps or overlaps
+        if c["first_frame"] != pos:
+            raise ValueError(f"chunk {c['file']} starts at frame {c['first_frame']}, expected {pos}")
+        pos += c["frames"]
+    merged = {"split": split, "world": world, "frames": pos, "params": parts[0]["params"] if parts else None, "chunks": chunks,
+              "regenerated": sorted(f for p in parts for f in p.get("regenerated", [])),
+              "summary": parts[0].get("summary") if parts else None}
+    with open(os.path.join(out_dir, f"{split}_manifest.json"), "w") as f:
+        json.dump(merged, f, indent=1)
+    return merged
+
+
+def load_merged(out_dir, split: str, keys=('rx_symbols', 'tx_symbols', 'H_ls', 'H_true', 'pilot_mask', 'snr_db', 'channel_type',
+                                           'doppler_hz', 'pilot_density')) -> Dict:
+    """The chunk files of a sharded job concatenated in global frame order (run_phase3_robust.py:261-288: the same key list)."""
+    import json
+    import os
+    man = json.load(open(os.path.join(out_dir, f"{split}_manifest.json")))
+    cols = {k: [] for k in keys}
+    for c in man["chunks"]:
+        with np.load(os.path.join(out_dir, c["file"]), allow_pickle=False) as z:
+            for k in keys:
+                cols[k].append(z[k])
+    return {k: np.concatenate(v, axis=0) for k, v in cols.items() if v}
+
+
 def main():
-    """CLI with the reference's flags (src/dataset_generator.py:230-315) plus --native."""
-    import yaml
+    """CLI with the reference's flags (src/dataset_generator.py:230-315) plus the sharded native job (BASELINE config 4):
+
+        python -m <package>.dataset_generator --config cfg.yaml --output-dir out --native --to-files --gpus 8
+
+    starts one rank per GPU itself (or runs under ``python -m torch.distributed.run``, whose RANK / LOCAL_RANK / WORLD_SIZE are
+    used as they are): every rank generates its contiguous frame range on the device RNG and streams it to chunk files, the
+    job ends with one gather of the per-frame records to rank 0, which writes the merged manifest."""
+    import os
+    import sys
     parser = argparse.ArgumentParser(description='Generate channel estimation dataset')
     parser.add_argument('--config', type=str, default='configs/experiment_config.yaml')
     parser.add_argument('--output-dir', type=str, default='data')
@@ -369,8 +454,25 @@ def main():
     parser.add_argument('--format', type=str, default='npz', choices=['npz', 'h5'])
     parser.add_argument('--seed', type=int, default=42)
     parser.add_argument('--native', action='store_true', help='device RNG + batched pipeline instead of the np.random replay')
+    parser.add_argument('--to-files', action='store_true',
+                        help='with --native: stream every rank\'s frame range to chunk files + manifests (datasets larger than host memory)')
+    parser.add_argument('--gpus', type=int, default=1, help='with --native --to-files: ranks of the job, one per GPU (started here unless a launcher set WORLD_SIZE)')
+    parser.add_argument('--dist-backend', default='nccl', choices=['nccl', 'gloo'],
+                        help='nccl (= RCCL, one GPU per rank); gloo rehearses the job with several ranks sharing a GPU')
+    parser.add_argument('--chunk-frames', type=int, default=4096)
+    parser.add_argument('--writers', type=int, default=8, help='background compression threads per rank')
+    parser.add_argument('--uncompressed', action='store_true', help='np.savez instead of np.savez_compressed for the chunk files')
+    parser.add_argument('--pattern-group', type=int, default=1, help='frames sharing a pilot pattern (1 = a new pattern per frame, as the reference)')
+    parser.add_argument('--splits', type=str, default='train,val,test')
     args = parser.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and not (args.native and args.to_files):
+        raise SystemExit("--gpus N shards the native streaming job: use it with --native --to-files")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(_spawn_ranks(args.gpus, sys.argv[1:]))                    # before anything here touches the GPU
     import random
+    import yaml
     import torch
     random.seed(args.seed); np.random.seed(args.seed); torch.manual_seed(args.seed)      # utils.set_seed
     with open(args.config, 'r') as f:
@@ -381,9 +483,44 @@ def main():
     out_dir = Path(args.output_dir)
     out_dir.mkdir(parents=True, exist_ok=True)
     gen = ChannelEstimationDataset(config)
-    for j, split in enumerate(('train', 'val', 'test')):
+    splits = [sp for sp in args.splits.split(',') if sp]
+    seed_of = {'train': args.seed, 'val': args.seed + 1, 'test': args.seed + 2}
+    if args.native and args.to_files:
+        import torch.distributed as dist
+        world = int(os.environ.get("WORLD_SIZE", "1"))
+        rank = int(os.environ.get("RANK", "0"))
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        if world != args.gpus:
+            raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+        ndev = max(1, torch.cuda.device_count())
+        torch.cuda.set_device(local % ndev if args.dist_backend == "gloo" else local)
+        if world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if args.dist_backend == "nccl":
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+            else:
+                dist.init_process_group("gloo", rank=rank, world_size=world)
+        for split in splits:
+            n = int(config['dataset'][f'{split}_samples'])
+            man = gen.generate_dataset_native_to_files(n, str(out_dir), split=split, seed=seed_of.get(split, args.seed), rank=rank, world=world,
+                                                       chunk_frames=args.chunk_frames, writers=args.writers, compressed=not args.uncompressed,
+                                                       pattern_group=args.pattern_group)
+            if world > 1:
+                dist.barrier()                                             # every rank's manifest is on disk
+            if rank == 0:
+                merged = merge_manifests(str(out_dir), split, world)
+                print(f"{split}: {merged['frames']} frames in {len(merged['chunks'])} chunk files from {world} rank(s); "
+                      f"regenerated {len(merged['regenerated'])}; summary {man.get('summary')}")
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        if rank == 0:
+            print("Dataset generation completed!")
+        return
+    for split in splits:
         n = config['dataset'][f'{split}_samples']
-        ds = gen.generate_dataset_native(n, seed=args.seed + j) if args.native else gen.generate_dataset(n, split)
+        ds = gen.generate_dataset_native(n, seed=seed_of.get(split, args.seed), pattern_group=args.pattern_group) if args.native \
+            else gen.generate_dataset(n, split)
         gen.save_dataset(ds, out_dir / f'{split}.{args.format}', format=args.format)
     print("Dataset generation completed!")
 

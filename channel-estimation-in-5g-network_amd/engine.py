@@ -41,9 +41,25 @@ class Geometry:
     subcarrier_spacing: float = 15000.0
     num_tx: int = 2
     num_rx: int = 2
+    num_subcarriers: int = 0      # > 0: an explicit (num_symbols x num_subcarriers) grid without OFDM numerology (``Geometry.grid_only``)
+
+    @classmethod
+    def grid_only(cls, num_symbols: int, num_subcarriers: int, num_tx: int, num_rx: int) -> "Geometry":
+        """Geometry of an explicit resource grid -- what the reference's estimator-side functions see: they take any (S, nsc), an
+        even subcarrier count included (src/baseline_estimators.py:83-117, src/channel_simulator.py:313-345).  The engine of such
+        a geometry (chest_create_grid) serves the estimators, apply_channel, equalize and the pattern / plan entry points; it has
+        no frame pipeline, OFDM modem or channel model."""
+        return cls(fft_size=0, cp_length=0, num_symbols=int(num_symbols), useful_subcarriers=0, subcarrier_spacing=0.0,
+                   num_tx=int(num_tx), num_rx=int(num_rx), num_subcarriers=int(num_subcarriers))
+
+    @property
+    def is_grid_only(self) -> bool:
+        return self.num_subcarriers > 0
 
     @property
     def num_sc(self) -> int:
+        if self.num_subcarriers > 0:
+            return self.num_subcarriers
         return 2 * (self.useful_subcarriers // 2) - 1
 
     @property
@@ -85,11 +101,16 @@ class Engine:
         self.geom = geometry
         self.device = torch.device("cuda", torch.cuda.current_device() if device is None else
                                    (device if isinstance(device, int) else torch.device(device).index or 0))
-        cfg = N.Config(geometry.fft_size, geometry.cp_length, geometry.num_symbols, geometry.useful_subcarriers,
-                       float(geometry.subcarrier_spacing), geometry.num_tx, geometry.num_rx, self.device.index)
         h = C.c_void_p()
-        N.check(N.lib().chest_create(C.byref(cfg), C.byref(h)), "chest_create")
+        if geometry.is_grid_only:
+            N.check(N.lib().chest_create_grid(geometry.num_symbols, geometry.num_subcarriers, geometry.num_tx, geometry.num_rx,
+                                              self.device.index, C.byref(h)), "chest_create_grid")
+        else:
+            cfg = N.Config(geometry.fft_size, geometry.cp_length, geometry.num_symbols, geometry.useful_subcarriers,
+                           float(geometry.subcarrier_spacing), geometry.num_tx, geometry.num_rx, self.device.index)
+            N.check(N.lib().chest_create(C.byref(cfg), C.byref(h)), "chest_create")
         self._h = h
+        self._profiles = {}       # channel_type code -> (delays, powers) uploaded with set_profile
         self._slots = {}          # pattern key -> slot
         self._slot_P = {}
         self._next_slot = 0
@@ -125,6 +146,19 @@ class Engine:
         p = (C.c_double * N.MAX_PATHS)()
         N.check(N.lib().chest_get_tap_table(self._h, channel_code(channel_type), C.byref(n), d, p), "chest_get_tap_table")
         return np.array(p[: n.value]), np.array(d[: n.value], dtype=np.int64)
+
+    def set_profile(self, channel_type, delays_s, powers_db):
+        """Replace the delay profile behind ``channel_type`` in THIS engine (chest_set_profile): an edited or added entry of the
+        reference's class-level ``ChannelModel.CHANNEL_PROFILES`` (src/channel_simulator.py:41-54, :72).  At most 16 paths and 9
+        distinct sample delays.  Synchronises."""
+        code = channel_code(channel_type)
+        d = np.ascontiguousarray(delays_s, dtype=np.float64).reshape(-1)
+        p = np.ascontiguousarray(powers_db, dtype=np.float64).reshape(-1)
+        if len(d) != len(p):
+            raise ValueError("delays and powers differ in length")
+        N.check(N.lib().chest_set_profile(self._h, code, len(d), d.ctypes.data_as(C.POINTER(C.c_double)),
+                                          p.ctypes.data_as(C.POINTER(C.c_double))), "chest_set_profile")
+        self._profiles[code] = (d.copy(), p.copy())
 
     # ---- patterns -----------------------------------------------------------------------------------
     def set_pattern(self, slot: int, pilot_idx, plan=None):

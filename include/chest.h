@@ -14,8 +14,8 @@
  *     row-major, complex64 stored as interleaved (re, im) float pairs, unless marked HOST.
  *   - launches are asynchronous on the caller's hipStream_t (passed as void*, NULL = default stream);
  *     no call in the "launch" group allocates, frees or synchronises (graph-capturable).
- *   - one context per (device, fft_size, cp_length, num_symbols, useful_subcarriers, num_tx, num_rx);
- *     a context is used by one host thread at a time.
+ *   - one context per (device, fft_size, cp_length, num_symbols, useful_subcarriers, num_tx, num_rx) -- or per explicit grid
+ *     (chest_create_grid); a context is used by one host thread at a time.
  *
  * Shapes use S = num_symbols, nsc = useful_subcarriers-1 (DC removed), T/R = tx/rx antennas,
  * P = pilots of the frame's pattern, G = S*nsc.
@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define CHEST_ABI_VERSION 2
+#define CHEST_ABI_VERSION 3
 
 #define CHEST_OK 0
 #define CHEST_EINVAL (-1)   /* bad argument / unsupported shape */
@@ -126,6 +126,21 @@ typedef struct chest_frame_outputs {
  * (src/channel_simulator.py:17-31, :56-82, :133-148). */
 int chest_create(const chest_config* cfg, chest_ctx** out);
 void chest_destroy(chest_ctx* ctx);
+/* A context over an explicit (num_symbols x num_subcarriers) resource grid WITHOUT an OFDM numerology.  The reference's estimator-side
+ * functions take any grid -- LSEstimator / MMSEEstimator.estimate (src/baseline_estimators.py:83-117, :232-270), MIMOChannel.apply_channel
+ * (src/channel_simulator.py:313-345), equalize_channel (:273-312) only read array shapes -- an EVEN subcarrier count included, which no
+ * (fft_size, useful_subcarriers) pair of chest_create produces (DC removal leaves an odd count).  Such a context serves the pattern
+ * entry points and chest_estimate_batch, chest_at_pilots, chest_error_sums, chest_apply_channel, chest_equalize, chest_mmse_full_*,
+ * chest_cubic_operator, chest_estimate_dense, chest_pack_ml_*; the entry points that need the numerology or the channel model
+ * (chest_frames_run, chest_ofdm_*, chest_time_varying_channel, chest_tdl_apply, chest_get_used_indices / _tap_table, chest_set_profile)
+ * return CHEST_ESTATE.  S <= CHEST_MAX_SYMBOLS, S * nsc <= 65535, 1..8 antennas. */
+int chest_create_grid(int32_t num_symbols, int32_t num_subcarriers, int32_t num_tx, int32_t num_rx, int32_t device, chest_ctx** out);
+/* Replace the delay profile behind one channel_type code of THIS context.  ChannelModel.CHANNEL_PROFILES is a class-level dict the
+ * reference reads at construction (src/channel_simulator.py:41-54, :72): callers edit an entry or add one.  delays_s (seconds) and
+ * powers_db: HOST arrays [num_paths], num_paths <= CHEST_MAX_PATHS, at most 9 distinct delays after rounding to samples; the arithmetic
+ * is ChannelModel.__init__'s (:72-82: powers normalised to sum 1, delay_samples = round-half-even(delays * fs), later paths overwrite
+ * earlier ones at the same delay).  Synchronises the device; every later launch of this context uses the new table. */
+int chest_set_profile(chest_ctx* ctx, int32_t channel_type, int32_t num_paths, const double* delays_s, const double* powers_db);
 const char* chest_last_error(void);
 int chest_abi_version(void);
 
@@ -330,8 +345,10 @@ int chest_bit_errors(chest_ctx* ctx, void* stream, int64_t n, const uint8_t* a, 
 int chest_mmse_full_prepare(chest_ctx* ctx, void* stream, int32_t num_pilots, const double* cov,
                             float snr_db, float* W, double* workspace, int64_t workspace_bytes);
 int64_t chest_mmse_full_workspace_bytes(int32_t num_pilots);
-/* DEVICE scratch chest_mmse_full_apply needs for num_grids = B*R*T right-hand sides (gathered h_ls and W repacked
- * to the GEMM's tile padding, plus the product). */
+/* DEVICE scratch chest_mmse_full_apply needs for num_grids = B*R*T right-hand sides: the gathered / padded h_ls [Mpad][Ppad] c64, the
+ * product [M][Ppad] c64, W in the filter GEMM's operand format (six fp16 planes [Npad][Ppad]) and the operand maxima (one word for W,
+ * one per 128-row tile of right-hand sides: the fp16 split scales every tile by a power of two taken from ITS OWN largest finite
+ * magnitude, so an absurd or non-finite value in one row cannot change the arithmetic of rows in other tiles). */
 int64_t chest_mmse_full_apply_scratch_bytes(int32_t num_pilots, int32_t num_grids);
 int chest_mmse_full_apply(chest_ctx* ctx, void* stream, int32_t num_frames, const float* rx4d,
                           const float* tx_pilots, int32_t pilot_stride, int32_t pattern_slot,

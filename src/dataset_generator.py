@@ -13,3 +13,6 @@ if _root not in _sys.path:
     _sys.path.insert(0, _root)
 _m = _il.import_module("channel-estimation-in-5g-network_amd.dataset_generator")
 globals().update({k: v for k, v in vars(_m).items() if not k.startswith("__")})
+
+if __name__ == "__main__":            # the reference's file is also a script (src/dataset_generator.py:318-319)
+    main()                             # noqa: F821 -- re-exported above

@@ -190,3 +190,55 @@ def test_dropin_estimators_and_native_dataset_share_an_engine_safely():
     b = gen.generate_dataset_native(12, seed=3, pattern_group=4)          # ... and takes the slots back again
     assert np.array_equal(a["H_ls"], b["H_ls"])
     assert np.max(np.abs(ls.estimate(rx4, x, mask, pos) - want)) / scale < 1e-5
+
+
+def test_config4_as_a_program_two_gloo_ranks_share_the_gpu(tmp_path):
+    """BASELINE config 4 as ONE command: `dataset_generator --native --to-files --gpus 2` starts its two ranks
+    itself (child processes; gloo, both on the one GPU), every rank streams its contiguous frame range to chunk files, the job's
+    gather goes to rank 0, which writes the merged manifest (the reference's chunk / merge scheme: run_phase3_robust.py:99-116,
+    :261-288; flags: src/dataset_generator.py:232-248).  The union of the chunk files equals the single-rank run bit for bit, and
+    deleting one chunk and re-running the same command regenerates exactly that chunk."""
+    import json
+    import os
+    import subprocess
+    import sys
+    import yaml
+    from conftest import ROOT
+    cfg = dict(CFG, dataset={"train_samples": 50, "val_samples": 9, "test_samples": 0})
+    cfg_path = tmp_path / "cfg.yaml"
+    yaml.safe_dump(cfg, open(cfg_path, "w"))
+    out = tmp_path / "out"
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    cmd = [sys.executable, os.path.join(ROOT, "src", "dataset_generator.py"), "--config", str(cfg_path), "--output-dir", str(out), "--native",
+           "--to-files", "--gpus", "2", "--dist-backend", "gloo", "--chunk-frames", "11", "--seed", "7", "--splits", "train,val",
+           "--writers", "2"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    assert "Dataset generation completed!" in p.stdout
+    man = json.load(open(out / "train_manifest.json"))
+    assert man["frames"] == 50 and man["world"] == 2 and man["summary"]["frames_all_ranks"] == 50
+    assert [c["first_frame"] for c in man["chunks"]] == [0, 11, 22, 25, 36, 47] and [c["rank"] for c in man["chunks"]] == [0, 0, 0, 1, 1, 1]
+    gen = dg.ChannelEstimationDataset(cfg)
+    whole = gen.generate_dataset_native(50, seed=7)                              # single rank, in this process
+    merged = dg.load_merged(str(out), "train", keys=("rx_symbols", "tx_symbols", "H_ls", "H_true", "pilot_mask", "snr_db",
+                                                      "channel_type", "doppler_hz", "pilot_density", "H_mmse", "frame_index"))
+    for k, v in merged.items():
+        assert np.array_equal(v, whole[k]), k
+    val = json.load(open(out / "val_manifest.json"))
+    assert val["frames"] == 9 and np.array_equal(dg.load_merged(str(out), "val")["H_ls"], gen.generate_dataset_native(9, seed=8)["H_ls"])
+    # resume: one chunk lost -> the same command regenerates exactly that chunk
+    files = sorted(f for f in os.listdir(out) if f.startswith("train_rank") and f.endswith(".npz"))
+    victim = out / "train_rank01_chunk0001.npz"
+    before = np.load(victim)["H_true"].copy()
+    mtimes = {f: os.path.getmtime(out / f) for f in files}
+    os.remove(victim)
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    assert np.array_equal(np.load(victim)["H_true"], before)
+    assert all(os.path.getmtime(out / f) == mtimes[f] for f in files if f != victim.name)
+    with pytest.raises(SystemExit):
+        sys.argv, saved = ["dataset_generator", "--gpus", "2"], sys.argv
+        try:
+            dg.main()                                                            # --gpus N needs --native --to-files
+        finally:
+            sys.argv = saved
