@@ -309,15 +309,14 @@ static int pattern_set_impl(chest_ctx* ctx, int32_t slot, const int32_t* pilot_i
             }
     const bool with_plan = plan_idx != nullptr || simplices != nullptr;
     CHEST_GUARD(ctx);
-    // draw slot of every resource element: i-th pilot <-> i-th True of the row-major mask
-    // (insert_pilots, src/channel_simulator.py:249-252); data symbols follow in row-major order.
-    std::vector<uint16_t> slots(G);
+    // pilot bit table (chest_internal.h PatternDev::bits): i-th pilot <-> i-th True of the row-major mask (insert_pilots,
+    // src/channel_simulator.py:249-252); data symbols follow in row-major order -- both ordinals follow from the ranks stored here.
+    const int W = pattern_bit_words(G);
+    std::vector<uint2> bits((size_t)W, make_uint2(0u, 0u));
+    for (int i = 0; i < P; ++i) bits[pilot_idx[i] >> 5].x |= 1u << (pilot_idx[i] & 31);
     {
-        int pi = 0, di = 0;
-        for (int g = 0; g < G; ++g) {
-            if (pi < P && pilot_idx[pi] == g) slots[g] = (uint16_t)pi++;
-            else slots[g] = (uint16_t)(P + di++);
-        }
+        uint32_t before = 0;
+        for (int w = 0; w < W; ++w) { bits[w].y = before; before += (uint32_t)__builtin_popcount(bits[w].x); }
     }
     auto up16 = [](size_t v) { return (v + 15) & ~(size_t)15; };
     struct Rec { float w0, w1; uint32_t i01, i2v; };
@@ -331,10 +330,10 @@ static int pattern_set_impl(chest_ctx* ctx, int32_t slot, const int32_t* pilot_i
             recs[g] = Rec{w0, w1, i0 | (i1 << 16), i2 | (valid << 16)};
         }
     }
-    // block layout: slot[G] u16 | pilot_idx[P] | simplices[ns][3] + their packed form (triangulation path) | plan[G] records (last, so the
+    // block layout: pilot bit table uint2[W] | pilot_idx[P] | simplices[ns][3] + their packed form (triangulation path) | plan[G] records (last, so the
     // triangulation path uploads everything before it in one copy and the device fills the plan)
     const size_t o_slot = 0;
-    const size_t o_pil = up16(o_slot + (size_t)G * 2);
+    const size_t o_pil = up16(o_slot + (size_t)W * sizeof(uint2));
     const size_t o_simp = up16(o_pil + (size_t)P * 4);
     const size_t o_pack = up16(o_simp + (simplices ? (size_t)ns * 12 : 0));            // packed simplices, written by the device
     const size_t o_plan = (o_pack + (simplices ? (size_t)ns * 16 : 0) + 255) & ~(size_t)255;
@@ -343,7 +342,7 @@ static int pattern_set_impl(chest_ctx* ctx, int32_t slot, const int32_t* pilot_i
     unsigned char* blk = nullptr;
     CHEST_HIP(hipMalloc((void**)&blk, total));
     std::vector<unsigned char> host(upload, 0);
-    memcpy(host.data() + o_slot, slots.data(), (size_t)G * 2);
+    memcpy(host.data() + o_slot, bits.data(), (size_t)W * sizeof(uint2));
     memcpy(host.data() + o_pil, pilot_idx, (size_t)P * 4);
     if (simplices) memcpy(host.data() + o_simp, simplices, (size_t)ns * 12);
     if (plan_idx) memcpy(host.data() + o_plan, recs.data(), (size_t)G * sizeof(Rec));
@@ -364,11 +363,11 @@ static int pattern_set_impl(chest_ctx* ctx, int32_t slot, const int32_t* pilot_i
     if (ph.block) { CHEST_HIP(hipDeviceSynchronize()); CHEST_HIP(hipFree(ph.block)); }
     ph.block = blk;
     ph.dev = PatternDev{};                                       // (a slot that held a compact plan must not keep its `pad`)
-    ph.dev.slot = (const uint16_t*)(blk + o_slot);
+    ph.dev.bits = (const uint2*)(blk + o_slot);
     ph.dev.plan = with_plan ? (const void*)(blk + o_plan) : nullptr;
     ph.dev.pilot_idx = (const int32_t*)(blk + o_pil);
     ph.dev.P = P;
-    // table entries between the old size and `slot` stay zero (slot == nullptr -> "not set")
+    // table entries between the old size and `slot` stay zero (bits == nullptr -> "not set")
     return upload_pattern_table_entry(ctx, slot);
 }
 
@@ -390,7 +389,7 @@ int chest_pattern_set_triangulation(chest_ctx* ctx, int32_t slot, const int32_t*
 }
 
 int chest_pattern_get_plan(chest_ctx* ctx, int32_t slot, uint16_t* plan_idx, float* plan_w) {
-    if (!ctx || slot < 0 || (size_t)slot >= ctx->patterns.size() || ctx->patterns[slot].dev.slot == nullptr) {
+    if (!ctx || slot < 0 || (size_t)slot >= ctx->patterns.size() || ctx->patterns[slot].dev.bits == nullptr) {
         set_error("pattern slot %d is not set", slot);
         return CHEST_ESTATE;
     }
@@ -434,7 +433,7 @@ int chest_pattern_get_plan(chest_ctx* ctx, int32_t slot, uint16_t* plan_idx, flo
 }
 
 int chest_pattern_num_pilots(chest_ctx* ctx, int32_t slot) {
-    if (!ctx || slot < 0 || (size_t)slot >= ctx->patterns.size() || ctx->patterns[slot].dev.slot == nullptr) {
+    if (!ctx || slot < 0 || (size_t)slot >= ctx->patterns.size() || ctx->patterns[slot].dev.bits == nullptr) {
         set_error("pattern slot %d is not set", slot);
         return CHEST_ESTATE;
     }
@@ -501,6 +500,7 @@ int chest_tune(chest_ctx* ctx, const char* key, int32_t value) {
     if (strcmp(key, "frame_rx_group") == 0) { ctx->tune_rx_group = value; return CHEST_OK; }
     if (strcmp(key, "frame_two_slabs") == 0) { ctx->tune_two_slabs = value < 0 ? -1 : 0; return CHEST_OK; }
     if (strcmp(key, "gemm_f32") == 0) { ctx->tune_gemm_f32 = value ? 1 : 0; return CHEST_OK; }
+    if (strcmp(key, "interp_xcd") == 0) { ctx->tune_interp_xcd = value < 0 ? -1 : 0; return CHEST_OK; }
     if (strcmp(key, "frame_store_extra") == 0) { ctx->tune_store_extra = (value >= -1 && value <= 4) ? value : 0; return CHEST_OK; }
     if (strcmp(key, "frame_store_waves") == 0) { ctx->tune_store_waves = (value >= 0 && value <= 16) ? value : 0; return CHEST_OK; }
     if (strcmp(key, "frame_min_waves") == 0) { ctx->tune_min_waves = value; return CHEST_OK; }
@@ -571,15 +571,17 @@ int chest_time_varying_channel(chest_ctx* ctx, void* stream, int32_t type, float
 }
 
 int chest_ofdm_modulate(chest_ctx* ctx, void* stream, int32_t n, const float* sym, float* out) {
-    if (!ctx || n < 0 || (n > 0 && (!sym || !out))) { set_error("chest_ofdm_modulate: bad argument"); return CHEST_EINVAL; }
+    if (!ctx) { set_error("chest_ofdm_modulate: null context"); return CHEST_EINVAL; }
     CHEST_NEEDS_OFDM(ctx, "chest_ofdm_modulate");
+    if (n < 0 || (n > 0 && (!sym || !out))) { set_error("chest_ofdm_modulate: bad argument"); return CHEST_EINVAL; }
     CHEST_GUARD(ctx);
     return launch_ofdm(ctx, (hipStream_t)stream, n, sym, out, true);
 }
 
 int chest_ofdm_demodulate(chest_ctx* ctx, void* stream, int32_t n, const float* tin, float* out) {
-    if (!ctx || n < 0 || (n > 0 && (!tin || !out))) { set_error("chest_ofdm_demodulate: bad argument"); return CHEST_EINVAL; }
+    if (!ctx) { set_error("chest_ofdm_demodulate: null context"); return CHEST_EINVAL; }
     CHEST_NEEDS_OFDM(ctx, "chest_ofdm_demodulate");
+    if (n < 0 || (n > 0 && (!tin || !out))) { set_error("chest_ofdm_demodulate: bad argument"); return CHEST_EINVAL; }
     CHEST_GUARD(ctx);
     return launch_ofdm(ctx, (hipStream_t)stream, n, tin, out, false);
 }

@@ -99,6 +99,20 @@ struct PlanRec { float w0, w1; uint32_t i01, i2v; };
 #define CHEST_GLOBAL __attribute__((address_space(1)))
 typedef const CHEST_GLOBAL uint16_t* gptr_u16;
 typedef const CHEST_GLOBAL int32_t* gptr_i32;
+typedef uint32_t v2u_t __attribute__((ext_vector_type(2)));
+typedef const CHEST_GLOBAL v2u_t* gptr_bits;
+// draw slot of resource element g from the pattern's pilot bit table (chest_internal.h: PatternDev::bits): < P = pilot ordinal
+__device__ __forceinline__ uint32_t draw_slot(gptr_bits bits, int g, int P) {
+    const v2u_t w = bits[g >> 5];
+    const uint32_t sh = (uint32_t)g & 31u;
+    const uint32_t rank = w.y + (uint32_t)__popc(w.x & ((1u << sh) - 1u));
+    return ((w.x >> sh) & 1u) ? rank : (uint32_t)P + (uint32_t)g - rank;
+}
+// bits g .. g + 15 of the pilot mask (g + 15 may run into the next word; the table carries one zero word of padding)
+__device__ __forceinline__ uint32_t mask_bits16(gptr_bits bits, int g) {
+    const uint64_t ww = (uint64_t)bits[g >> 5].x | ((uint64_t)bits[(g >> 5) + 1].x << 32);
+    return (uint32_t)(ww >> (g & 31)) & 0xFFFFu;
+}
 typedef uint32_t v4u_t __attribute__((ext_vector_type(4)));
 typedef const CHEST_GLOBAL v4u_t* gptr_plan;
 __device__ __forceinline__ PlanRec ld_plan(gptr_plan plan, int i) {     // one 16-B global load

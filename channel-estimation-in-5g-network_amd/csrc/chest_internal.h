@@ -41,8 +41,14 @@ struct FrameParams {               // passed by value (kernarg segment -> scalar
     TapProfile prof[CHEST_NUM_PROFILES];
 };
 
+// Which resource elements are pilots, 8 bytes per 32 elements: word w = {bit mask of elements 32 w .. 32 w + 31, number of pilots
+// before element 32 w}.  The draw slot of element g (insert_pilots order, src/channel_simulator.py:249-252: the i-th pilot is the
+// i-th True of the row-major mask, the data symbols follow in row-major order) is rank = .y + popcount(.x below bit g & 31) for a
+// pilot and P + g - rank for a data element (chest_device.h: draw_slot).  [G / 32 rounded up, + 1 zero word]: 2.1 KB per 14 x 599
+// pattern (round 5; a u16 slot per element was 16.8 KB of every per-frame pattern's 64 KB).
+__host__ __device__ inline int pattern_bit_words(int G) { return (G + 31) / 32 + 1; }
 struct PatternDev {
-    const uint16_t* slot;          // [G] draw slot of each RE: < P pilot ordinal, else P + data ordinal
+    const uint2* bits;             // [pattern_bit_words(G)]; nullptr: slot not set
     const void* plan;              // [G] 16-B records {w0, w1, i0|i1<<16, i2|valid<<16} or nullptr; compact plans: [2 Pcap] triangle records
     const int32_t* pilot_idx;      // [P]
     int32_t P;
@@ -88,6 +94,7 @@ struct chest_ctx {
     // chest_tune (tools / experiments only; nothing on the launch path reads the environment)
     int32_t tune_rx_group = 0;            // rx antennas per slab unit of the frame kernel (0 = chosen from the LDS budget)
     int32_t tune_taps_threads = 0;        // taps kernel workgroup size 64 / 128 / 256 (0 = by antenna count)
+    int32_t tune_interp_xcd = 0;          // -1: interp_from_pilots_tfold_kernel without the XCD-contiguous row ranges (A/B)
     int32_t tune_gemm_f32 = 0;            // 1: the full-covariance filter on the exact-f32 MFMA kernel (cgemm_w_kernel_3m) instead of the fp16-split one (A/B)
     int32_t tune_two_slabs = 0;           // -1: no second slab for the one-workgroup-per-CU frame kernel (A/B)
     int32_t tune_store_extra = 0;         // dedicated store waves per frame workgroup (0 = the default of the launcher, -1 = none); experiments

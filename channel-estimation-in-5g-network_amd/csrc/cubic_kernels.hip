@@ -206,7 +206,7 @@ extern "C" int64_t chest_cubic_workspace_bytes(chest_ctx* ctx, int32_t num_pilot
 extern "C" int chest_cubic_operator(chest_ctx* ctx, void* stream, int32_t slot, const int32_t* simplices, const int32_t* neighbors,
                                     int32_t num_simplices, float* A, void* workspace, int64_t workspace_bytes) {
     if (!ctx || !simplices || !neighbors || num_simplices < 1 || !A || !workspace) { set_error("chest_cubic_operator: bad argument"); return CHEST_EINVAL; }
-    if (slot < 0 || (size_t)slot >= ctx->patterns.size() || ctx->patterns[slot].dev.slot == nullptr) {
+    if (slot < 0 || (size_t)slot >= ctx->patterns.size() || ctx->patterns[slot].dev.bits == nullptr) {
         set_error("pattern slot %d is not set", slot);
         return CHEST_ESTATE;
     }

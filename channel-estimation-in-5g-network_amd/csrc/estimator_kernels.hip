@@ -53,7 +53,7 @@ estimate_kernel(int S, int R, int T, int nsc, const PatternDev* __restrict__ pat
 int launch_estimate(chest_ctx* ctx, hipStream_t st, int32_t B, const float* rx4d, const float* tx_pilots,
                     int32_t pilot_stride, int32_t slot, int32_t mmse, float snr_db, float* H_est) {
     if (B <= 0) return CHEST_OK;
-    if (slot < 0 || slot >= (int)ctx->patterns.size() || ctx->patterns[slot].dev.slot == nullptr) {
+    if (slot < 0 || slot >= (int)ctx->patterns.size() || ctx->patterns[slot].dev.bits == nullptr) {
         set_error("pattern slot %d is not set", slot);
         return CHEST_ESTATE;
     }

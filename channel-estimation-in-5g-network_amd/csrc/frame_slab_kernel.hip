@@ -24,7 +24,7 @@ namespace chest {
 typedef float v4f_t __attribute__((ext_vector_type(4)));
 typedef float v2f_t __attribute__((ext_vector_type(2)));
 
-// Output tensors are written once and never read back: nontemporal stores (tools/micro/store_flavour.hip).
+// Output tensors are written once and never read back: nontemporal stores (tools/archive/micro/store_flavour.hip).
 __device__ __forceinline__ void st16(float2* p, float4 v) {
     const v4f_t t = {v.x, v.y, v.z, v.w};
     __builtin_nontemporal_store(t, (v4f_t*)p);
@@ -176,7 +176,7 @@ __device__ __forceinline__ void slab_body(const SlabArgs& A) {
     const float* __restrict__ usym = (INJ && inj.u_sym) ? inj.u_sym + (size_t)b * G : nullptr;
     const float* __restrict__ nre = (INJ && inj.n_re) ? inj.n_re + (size_t)b * S * R * nsc : nullptr;
     const float* __restrict__ nim = (INJ && inj.n_im) ? inj.n_im + (size_t)b * S * R * nsc : nullptr;
-    const gptr_u16 slots = (gptr_u16)pat.slot;
+    const gptr_bits pbits = (gptr_bits)pat.bits;
     // parity (element offset & 1) of the frame's first element in each tensor; 16-B-aligned tensor bases (host-checked)
     const int par_tx = (int)(((size_t)b * S * T * nsc) & 1), par_rx = (int)(((size_t)b * S * R * nsc) & 1),
               par_h = (int)(((size_t)b * S * R * T * nsc) & 1);
@@ -274,7 +274,7 @@ __device__ __forceinline__ void slab_body(const SlabArgs& A) {
 #pragma unroll
         for (int ss = 0; ss < SSN; ++ss) {
             const int sy = ss < S ? ss : S - 1;
-            sln[ss][0] = slots[sy * nsc + kc0]; sln[ss][1] = slots[sy * nsc + kc1];
+            sln[ss][0] = draw_slot(pbits, sy * nsc + kc0, P); sln[ss][1] = draw_slot(pbits, sy * nsc + kc1, P);
         }
     }
     f16v_t hacc[MF ? 4 : 1];                                      // MF: a symbol's H, all antenna pairs, this lane's subcarrier pair
@@ -332,10 +332,10 @@ __device__ __forceinline__ void slab_body(const SlabArgs& A) {
             if constexpr (INJ) {
                 sc[ss][0] = sln[ss][0]; sc[ss][1] = sln[ss][1];
                 const int sn = sb + SSN + ss;
-                if (sn < S) { sln[ss][0] = slots[sn * nsc + kc0]; sln[ss][1] = slots[sn * nsc + kc1]; }
+                if (sn < S) { sln[ss][0] = draw_slot(pbits, sn * nsc + kc0, P); sln[ss][1] = draw_slot(pbits, sn * nsc + kc1, P); }
             } else {
                 const int sy = sb + ss < S ? sb + ss : S - 1;
-                sc[ss][0] = slots[sy * nsc + kc0]; sc[ss][1] = slots[sy * nsc + kc1];
+                sc[ss][0] = draw_slot(pbits, sy * nsc + kc0, P); sc[ss][1] = draw_slot(pbits, sy * nsc + kc1, P);
             }
             float u0, u1;
             if (usym != nullptr) {
@@ -521,28 +521,47 @@ __device__ __forceinline__ void slab_body(const SlabArgs& A) {
     __syncthreads();                                                             // hp complete; last store-out has read the slab
     STAMP_ADD(5);                                                                // barrier after phase W
 
-    // ---- pilot symbols in pilot order: regenerated from their own draws (identical arithmetic), linear 16-B stores ----
+    // ---- pilot symbols in pilot order: regenerated from their own draws (identical arithmetic) -------------------------
     if (out.pilot_symbols != nullptr) {
         float2* __restrict__ psb = (float2*)out.pilot_symbols + (size_t)b * out.pilot_stride;
-        const bool al = (((uintptr_t)psb) & 15) == 0;
-        for (int i = 2 * tid; i < P; i += 2 * (int)blockDim.x) {
-            float2 xs2[2];
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int p = i + j < P ? i + j : P - 1;
-                float u;
-                if (usym != nullptr) {
-                    u = usym[p];                                                 // first P draws are the pilot phases (:395)
-                } else {
-                    const int g = ((gptr_i32)pat.pilot_idx)[p];
+        if constexpr (CP) {
+            // A pattern of its own per frame: no read of its pilot index list (3.4 KB from HBM per frame).  One word of the pilot bit
+            // table per thread: its pilots have consecutive ordinals (.y, .y + 1, ...), the lanes of a wave write one ascending run.
+            const int W = (G + 31) >> 5;
+            for (int wi = tid; wi < W; wi += (int)blockDim.x) {
+                const v2u_t wv = pbits[wi];
+                uint32_t ord = wv.y;
+                for (uint32_t mm = wv.x; mm != 0; mm &= mm - 1) {
+                    const int g = (wi << 5) + (__ffs(mm) - 1);
                     const int sy = g / nsc, k = g - sy * nsc;
-                    const u32x4 z = draw(A.key, STREAM_SYM, (uint32_t)(sy * npair + (k >> 1)));
-                    u = u01((k & 1) ? z.y : z.x);
+                    float u;
+                    if (usym != nullptr) u = usym[ord];                          // first P draws are the pilot phases (:395)
+                    else { const u32x4 z = draw(A.key, STREAM_SYM, (uint32_t)(sy * npair + (k >> 1))); u = u01((k & 1) ? z.y : z.x); }
+                    st8(psb + ord, cis_unit(__builtin_amdgcn_fractf(u)));
+                    ++ord;
                 }
-                xs2[j] = cis_unit(__builtin_amdgcn_fractf(u));
             }
-            if (al && i + 1 < P) st16(psb + i, make_float4(xs2[0].x, xs2[0].y, xs2[1].x, xs2[1].y));
-            else { st8(psb + i, xs2[0]); if (i + 1 < P) st8(psb + i + 1, xs2[1]); }
+        } else {
+            const bool al = (((uintptr_t)psb) & 15) == 0;
+            for (int i = 2 * tid; i < P; i += 2 * (int)blockDim.x) {             // shared patterns (tables in L2): linear 16-B stores
+                float2 xs2[2];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int p = i + j < P ? i + j : P - 1;
+                    float u;
+                    if (usym != nullptr) {
+                        u = usym[p];                                             // first P draws are the pilot phases (:395)
+                    } else {
+                        const int g = ((gptr_i32)pat.pilot_idx)[p];
+                        const int sy = g / nsc, k = g - sy * nsc;
+                        const u32x4 z = draw(A.key, STREAM_SYM, (uint32_t)(sy * npair + (k >> 1)));
+                        u = u01((k & 1) ? z.y : z.x);
+                    }
+                    xs2[j] = cis_unit(__builtin_amdgcn_fractf(u));
+                }
+                if (al && i + 1 < P) st16(psb + i, make_float4(xs2[0].x, xs2[0].y, xs2[1].x, xs2[1].y));
+                else { st8(psb + i, xs2[0]); if (i + 1 < P) st8(psb + i + 1, xs2[1]); }
+            }
         }
     }
     if (out.h_ls_pilots != nullptr) {                // LS estimates at the pilots, [R][stride] per frame, zero padded
@@ -791,7 +810,7 @@ frame_slab_kernel(const FrameParams* __restrict__ fpp, const chest_frame_desc* _
     };
     if (rec[ST_VALID] == 0.f) { fail_frame(); return; }          // K1 flagged the descriptor (uniform exit)
     const PatternDev pat = patterns[fd.pattern_slot];
-    if (pat.slot == nullptr) {
+    if (pat.bits == nullptr) {
         if (tid == 0) { atomicExch(status, 1); if (out.frame_status) out.frame_status[b] = 1; }
         fail_frame();
         return;
@@ -802,8 +821,6 @@ frame_slab_kernel(const FrameParams* __restrict__ fpp, const chest_frame_desc* _
         fail_frame();
         return;
     }
-    const int P = pat.P;
-
     // Compact plans belong to ONE frame and come from HBM.  A read that misses the caches while the chip is saturated with
     // this kernel's stores waits microseconds, and the estimate phase would meet one such wait per unit (2.94 ms per 10 000
     // frames, against 2.0 ms when the tables are cached).  The tables are small enough -- 44 KB at 14 x 599 -- to be pulled in
@@ -821,37 +838,37 @@ frame_slab_kernel(const FrameParams* __restrict__ fpp, const chest_frame_desc* _
 
     // ---- pilot mask: 16 resource elements per thread and one 16-B store, after peeling the row to 16-B alignment
     //      (G is rarely a multiple of 16, so most rows start misaligned) ---------------------------------------------
-    const gptr_u16 gslot = (gptr_u16)pat.slot;
+    const gptr_bits gbits = (gptr_bits)pat.bits;
+    auto is_pilot = [&](int g) -> uint32_t { return (gbits[g >> 5].x >> (g & 31)) & 1u; };
     if (out.pilot_mask != nullptr) {
         uint8_t* mrow = out.pilot_mask + (size_t)b * G;
         const int lead = min(G, (int)((16 - ((uintptr_t)mrow & 15)) & 15));
         const int nvec = (G - lead) >> 4, tail0 = lead + (nvec << 4);
-        if (tid < lead) mrow[tid] = gslot[tid] < P ? 1 : 0;
+        if (tid < lead) mrow[tid] = (uint8_t)is_pilot(tid);
         for (int v = tid; v < nvec; v += blockDim.x) {
-            const gptr_u16 sp = gslot + lead + (v << 4);
+            const uint32_t m16 = mask_bits16(gbits, lead + (v << 4));
             uint32_t wq[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                wq[q] = 0;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) wq[q] |= (sp[4 * q + j] < P ? 1u : 0u) << (8 * j);
+                const uint32_t n = (m16 >> (4 * q)) & 0xFu;                   // four mask bits -> four 0/1 bytes
+                wq[q] = (n & 1u) | ((n & 2u) << 7) | ((n & 4u) << 14) | ((n & 8u) << 21);
             }
             *(uint4*)(mrow + lead + (v << 4)) = make_uint4(wq[0], wq[1], wq[2], wq[3]);
         }
-        if (tid < G - tail0) mrow[tail0 + tid] = gslot[tail0 + tid] < P ? 1 : 0;
+        if (tid < G - tail0) mrow[tail0 + tid] = (uint8_t)is_pilot(tail0 + tid);
     }
     // the same mask as float32 0/1 (the dataset schema of run_phase3_dataset_generation.py:139): 4 elements per 16-B store
     if (out.pilot_mask_f32 != nullptr) {
         float* mrow = out.pilot_mask_f32 + (size_t)b * G;
         const int lead = min(G, (int)(((16 - ((uintptr_t)mrow & 15)) & 15) >> 2));
         const int nvec = (G - lead) >> 2, tail0 = lead + (nvec << 2);
-        if (tid < lead) mrow[tid] = gslot[tid] < P ? 1.f : 0.f;
+        if (tid < lead) mrow[tid] = is_pilot(tid) ? 1.f : 0.f;
         for (int v = tid; v < nvec; v += blockDim.x) {
-            const gptr_u16 sp = gslot + lead + (v << 2);
-            const v4f_t m = {sp[0] < P ? 1.f : 0.f, sp[1] < P ? 1.f : 0.f, sp[2] < P ? 1.f : 0.f, sp[3] < P ? 1.f : 0.f};
+            const uint32_t m4 = mask_bits16(gbits, lead + (v << 2));
+            const v4f_t m = {(m4 & 1u) ? 1.f : 0.f, (m4 & 2u) ? 1.f : 0.f, (m4 & 4u) ? 1.f : 0.f, (m4 & 8u) ? 1.f : 0.f};
             __builtin_nontemporal_store(m, (v4f_t*)(mrow + lead + (v << 2)));
         }
-        if (tid < G - tail0) mrow[tail0 + tid] = gslot[tail0 + tid] < P ? 1.f : 0.f;
+        if (tid < G - tail0) mrow[tail0 + tid] = is_pilot(tail0 + tid) ? 1.f : 0.f;
     }
 
     if constexpr (CP) asm volatile("" :: "v"(touch0), "v"(touch1));          // the touches have landed (nothing else uses their values)

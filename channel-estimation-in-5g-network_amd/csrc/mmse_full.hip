@@ -426,6 +426,9 @@ interp_from_pilots_kernel(int S, int R, int T, int nsc, int Ppad, const PatternD
     }
 }
 
+// (Round 5, measured and dropped: TWO row buffers and one barrier per symbol, so that symbol s + 1 is interpolated while slower waves
+//  still stream symbol s -- 0.970-0.982 ms per 2 304 config-5 frames against 0.951-0.966 for this one-buffer form in the same process
+//  (profiles/r05_interp_two_rows_ab.txt): the second buffer costs two of the six workgroups a CU holds.)
 // The tx-replicated form of the pipeline route (one workgroup per (frame, rx)) with the frame kernel's write path: a symbol's
 // nsc interpolated values are staged in LDS once, and the T identical rows H_est[b][s][r][0..T) -- ONE contiguous span of
 // T * nsc elements -- leave as consecutive 128-B-line-aligned 1 KiB wave stores that read the LDS row modulo nsc.
@@ -433,10 +436,17 @@ typedef float v4f_i __attribute__((ext_vector_type(4)));
 typedef float v2f_i __attribute__((ext_vector_type(2)));
 __global__ void __launch_bounds__(256)
 interp_from_pilots_tfold_kernel(int S, int R, int T, int nsc, int Ppad, const PatternDev* __restrict__ patterns, int slot,
-                                const float2* __restrict__ h, float2* __restrict__ H_est) {
+                                const float2* __restrict__ h, float2* __restrict__ H_est, int xcd_ranges) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const PatternDev pat = patterns[slot];
-    const int P = pat.P, m = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int P = pat.P, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int m = blockIdx.x;
+    if (xcd_ranges) {
+        // Workgroups are dealt round-robin over the 8 XCDs: give each XCD a contiguous range of (frame, rx) rows, as the frame kernel
+        // does with its frames -- the four rx spans of a (frame, symbol) then leave through one L2 and an XCD's writes are one region.
+        const int nwg = gridDim.x, q = nwg >> 3, rr = nwg & 7, x = m & 7;
+        m = (x < rr ? x * (q + 1) : rr * (q + 1) + (x - rr) * q) + (m >> 3);
+    }
     float2* hp = (float2*)lds_raw;                                  // [P rounded up to even]
     float2* row = hp + ((P + 1) & ~1);                              // [nsc]
     const int r = m % R, b = m / R;
@@ -692,7 +702,7 @@ int chest_mmse_full_apply(chest_ctx* ctx, void* stream, int32_t B, const float* 
         return CHEST_EINVAL;
     }
     if (B == 0) return CHEST_OK;
-    if (slot < 0 || slot >= (int)ctx->patterns.size() || ctx->patterns[slot].dev.slot == nullptr ||
+    if (slot < 0 || slot >= (int)ctx->patterns.size() || ctx->patterns[slot].dev.bits == nullptr ||
         ctx->patterns[slot].dev.plan == nullptr || ctx->patterns[slot].dev.pad != 0) {
         set_error("pattern slot %d is not set, has no plan or carries a compact plan", slot);
         return CHEST_ESTATE;
@@ -726,7 +736,7 @@ int chest_mmse_full_apply(chest_ctx* ctx, void* stream, int32_t B, const float* 
 static int full_pilots_check(chest_ctx* ctx, const char* who, int32_t B, int32_t slot, const void* scratch) {
     if (!ctx || B < 0 || (B > 0 && !scratch)) { set_error("%s: bad argument", who); return CHEST_EINVAL; }
     if (B == 0) return CHEST_OK;
-    if (slot < 0 || slot >= (int)ctx->patterns.size() || ctx->patterns[slot].dev.slot == nullptr ||
+    if (slot < 0 || slot >= (int)ctx->patterns.size() || ctx->patterns[slot].dev.bits == nullptr ||
         ctx->patterns[slot].dev.plan == nullptr || ctx->patterns[slot].dev.pad != 0) {
         set_error("pattern slot %d is not set, has no plan or carries a compact plan", slot);
         return CHEST_ESTATE;
@@ -803,7 +813,7 @@ int chest_mmse_full_interp_pilots(chest_ctx* ctx, void* stream, int32_t B, int32
     CHEST_LDS_OPT_IN(ctx, LDS_INTERP_TFOLD, interp_from_pilots_tfold_kernel, lds);
     const int sp_int = prof_open(ctx, st, CHEST_K_INTERP);
     hipLaunchKernelGGL(interp_from_pilots_tfold_kernel, dim3(M), dim3(256), lds, st, f.S, f.R, f.T, f.nsc, Ppad, ctx->d_patterns,
-                       slot, h_out, (float2*)H_est);
+                       slot, h_out, (float2*)H_est, ctx->tune_interp_xcd >= 0 ? 1 : 0);
     prof_close(ctx, st, sp_int);
     CHEST_HIP(hipGetLastError());
     return CHEST_OK;
@@ -829,7 +839,7 @@ int chest_estimate_dense(chest_ctx* ctx, void* stream, int32_t B, const float* r
         return CHEST_EINVAL;
     }
     if (B == 0) return CHEST_OK;
-    if (slot < 0 || slot >= (int)ctx->patterns.size() || ctx->patterns[slot].dev.slot == nullptr) {
+    if (slot < 0 || slot >= (int)ctx->patterns.size() || ctx->patterns[slot].dev.bits == nullptr) {
         set_error("pattern slot %d is not set", slot);
         return CHEST_ESTATE;
     }

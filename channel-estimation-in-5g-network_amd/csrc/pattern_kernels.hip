@@ -10,7 +10,8 @@
 //   1. pilot selection: every resource element gets a Philox key (seed, pattern id, element); the P smallest keys (ties by
 //      element index) are the pilots -- the order statistics of a random permutation, i.e. the same distribution as the
 //      reference's shuffle-and-take-P.  (Or the caller supplies the sorted pilot list.)
-//   2. slot table (draw slot of every resource element) by binary search in the sorted pilot list.
+//   2. pilot bit table: per 32 resource elements their pilot mask and the number of pilots before them (the draw slot of an
+//      element follows from a popcount: chest_device.h draw_slot).
 //   3. initial triangulation.  Pilots are lattice points on S parallel rows: each strip between two consecutive occupied
 //      rows is triangulated by merging the two sorted rows; the step number of every triangle and of its three neighbours
 //      follows from rank arithmetic (two binary searches per triangle, all triangles in parallel).  The pockets between the
@@ -43,7 +44,7 @@ constexpr int PB_MAX_ROWS = CHEST_MAX_SYMBOLS;
 
 struct PatBuildArgs {
     PatternDev* table;            // device pattern table; entries first_slot + j are written by the kernel
-    unsigned char* pool;          // count blocks of `stride` bytes: slot u16[G] | pilot_idx i32[Pcap] | plan PlanRec[G]
+    unsigned char* pool;          // count blocks of `stride` bytes: pilot bit table uint2[G / 32 + 1] | pilot_idx i32[Pcap] | plan PlanRec[G]
     size_t stride, o_pil, o_plan, o_tri;   // o_tri: compact plans only (method 2): u16 triangle id per element behind the record table
     const int32_t* num_pilots;    // [count]
     const int32_t* given_idx;     // [count][idx_stride] sorted flat indices, or nullptr: draw them
@@ -216,12 +217,12 @@ pattern_build_kernel(const PatBuildArgs A) {
     const int S = A.S, nsc = A.nsc, G = S * nsc;
     const int P = A.num_pilots[j];
     unsigned char* base = A.pool + (size_t)j * A.stride;
-    uint16_t* __restrict__ slotp = (uint16_t*)base;
+    uint2* __restrict__ bitsp = (uint2*)base;
     int32_t* __restrict__ pil = (int32_t*)(base + A.o_pil);
     PlanRec* __restrict__ plan = (PlanRec*)(base + A.o_plan);
     if (tid == 0) {
         PatternDev pd;
-        pd.slot = slotp; pd.plan = A.method >= 0 ? (const void*)plan : nullptr; pd.pilot_idx = pil; pd.P = P;
+        pd.bits = bitsp; pd.plan = A.method >= 0 ? (const void*)plan : nullptr; pd.pilot_idx = pil; pd.P = P;
         pd.pad = COMPACT ? (int32_t)(A.o_tri - A.o_plan) : 0;       // compact plan: bytes from the triangle records to the per-element ids
         A.table[A.first_slot + j] = pd;
         if (A.nsimp_out) A.nsimp_out[j] = 0;
@@ -351,30 +352,25 @@ pattern_build_kernel(const PatBuildArgs A) {
 
     PSTAMP(0);                                                   // pilot selection
     if (A.stop_after == 1) return;
-    // ================= 2. slot table ==============================================================================
-    // Assembled in LDS (the triangle area is still free) and written out as whole 16-B vectors: a thread's own elements are
-    // consecutive, so direct 2-byte stores would touch a different cache line from every lane.
+    // ================= 2. pilot bit table ==========================================================================
+    // {mask of 32 elements, pilots before them} per word (PatternDev::bits): every pilot sets its bit in LDS (the triangle area is
+    // still free), one thread per word scans the popcounts, 8-B stores.  (Rounds 1-4 wrote a u16 draw slot per element here: 16.8 KB
+    // of a 14 x 599 pattern's 64 KB, 3 000 vector instructions of its 94 000.)
     {
-        const unsigned big_bytes = (unsigned)max((size_t)4 * A.Pcap + 16 + (size_t)2 * A.Pcap * sizeof(TriRec), (size_t)4 * (SEL_BINS + 2 * SEL_LIST));
-        const bool staged = 2u * (unsigned)G + 16u <= big_bytes - (off_tr - off_big);     // uniform
-        uint16_t* __restrict__ stg = (uint16_t*)(lds_raw + off_tr);
-        int g = g_lo;
-        int s = g / nsc, k = g - s * nsc;
-        int pos = g < g_hi ? count_less(pts, P, ((uint32_t)s << 16) | (uint32_t)k) : 0;      // pilots before the block
-        uint32_t nextp = pos < P ? pts[pos] : 0xFFFFFFFFu;
-        for (; g < g_hi; ++g) {
-            const uint32_t key = ((uint32_t)s << 16) | (uint32_t)k;
-            uint16_t v;
-            if (key == nextp) { v = (uint16_t)pos; ++pos; nextp = pos < P ? pts[pos] : 0xFFFFFFFFu; }
-            else v = (uint16_t)(P + (g - pos));
-            if (staged) stg[g] = v; else slotp[g] = v;
-            if (++k == nsc) { k = 0; ++s; }
-        }
-        if (staged) {
-            __syncthreads();
-            const int nvec = (2 * G + 15) >> 4;                  // the slot region of a block is padded to 16 B
-            for (int v = tid; v < nvec; v += PB_THREADS) ((uint4*)slotp)[v] = ((const uint4*)stg)[v];
-        }
+        const int W = pattern_bit_words(G);                      // <= 2 049 words (G <= 65 535)
+        uint32_t* __restrict__ wm = (uint32_t*)(lds_raw + off_tr);
+        for (int w = tid; w < W; w += PB_THREADS) wm[w] = 0;
+        __syncthreads();
+        for (int i = tid; i < P; i += PB_THREADS) { const uint32_t g = (uint32_t)pil[i]; atomicOr(&wm[g >> 5], 1u << (g & 31u)); }
+        __syncthreads();
+        const int wper = (W + PB_THREADS - 1) / PB_THREADS;
+        const int w_lo = min(W, tid * wper), w_hi = min(W, w_lo + wper);
+        int mine = 0;
+        for (int w = w_lo; w < w_hi; ++w) mine += __popc(wm[w]);
+        const int2 ex = block_exscan<PB_THREADS>(mine, scan);
+        int before = ex.x;
+        for (int w = w_lo; w < w_hi; ++w) { const uint32_t m = wm[w]; bitsp[w] = make_uint2(m, (uint32_t)before); before += __popc(m); }
+        __syncthreads();                                         // (the LDS words are free again for the triangle records)
     }
     PSTAMP(1);                                                   // slot table
     if (A.stop_after == 2) return;
@@ -1063,7 +1059,7 @@ extern "C" int chest_patterns_build(chest_ctx* ctx, void* stream, int32_t first_
             if (ctx->patterns[s].block) { (void)hipFree(ctx->patterns[s].block); ctx->patterns[s] = PatternHost{}; }
         PatternPool pl{};
         pl.first_slot = first_slot; pl.count = count; pl.Pcap = Pmax;
-        pl.o_pil = up((size_t)G * 2, 16);
+        pl.o_pil = up((size_t)pattern_bit_words(G) * sizeof(uint2), 16);
         pl.o_plan = up(pl.o_pil + (size_t)Pmax * 4, 256);
         pl.compact = method == 2;
         if (pl.compact) {                                       // triangle records [2 Pmax] | u16 triangle id per element
@@ -1130,7 +1126,7 @@ extern "C" int chest_patterns_build(chest_ctx* ctx, void* stream, int32_t first_
             (void)hipFree(ph.block);
         }
         ph.block = nullptr;                                      // owned by the pool
-        ph.dev.slot = (const uint16_t*)base;
+        ph.dev.bits = (const uint2*)base;
         ph.dev.plan = method >= 0 ? (const void*)(base + pool->o_plan) : nullptr;
         ph.dev.pad = method == 2 ? (int32_t)(pool->o_tri - pool->o_plan) : 0;
         ph.dev.pilot_idx = (const int32_t*)(base + pool->o_pil);
@@ -1141,7 +1137,7 @@ extern "C" int chest_patterns_build(chest_ctx* ctx, void* stream, int32_t first_
 
 /* pilot list of a slot back to the host (sorted flat indices); synchronises on the device */
 extern "C" int chest_pattern_get_pilots(chest_ctx* ctx, int32_t slot, int32_t* pilot_idx_out) {
-    if (!ctx || !pilot_idx_out || slot < 0 || (size_t)slot >= ctx->patterns.size() || ctx->patterns[slot].dev.slot == nullptr) {
+    if (!ctx || !pilot_idx_out || slot < 0 || (size_t)slot >= ctx->patterns.size() || ctx->patterns[slot].dev.bits == nullptr) {
         set_error("pattern slot %d is not set", slot);
         return CHEST_ESTATE;
     }

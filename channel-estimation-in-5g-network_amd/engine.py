@@ -440,7 +440,7 @@ class Engine:
         On MI355X the rate at which the frame kernel's concurrent write streams drain depends on the physical placement
         of the buffers it writes: the same kernel, process and clock measures 2.35 to 3.3 ms per 10 000 frames depending
         only on which allocations it was handed (tools/placement_test.py; a pure-store model shows the same two levels,
-        about 5.2 and 6.7 TB/s, per tensor group: tools/micro/store_placement.hip).  A long-running job writes into the
+        about 5.2 and 6.7 TB/s, per tensor group: tools/archive/micro/store_placement.hip).  A long-running job writes into the
         same buffers for every batch, so it pays to pick them once: this allocates ``tries`` candidate sets per group
         (synthesis tensors tx/rx/H/..., estimate tensors H_ls/H_mmse; all kept alive meanwhile, so each gets different
         memory), times the complete kernel on every combination with the library's HIP events, keeps the fastest

@@ -443,3 +443,22 @@ def test_device_plan_divergence_from_griddata_is_measured_and_bounded(P):
     assert r["H_mmse"]["re_frac_gt_1e5"] < 0.05 and r["H_mmse"]["rel_l2"] < 0.05
     assert r["mse_rel_delta_ls"]["mean"] < 3e-3 and r["mse_rel_delta_ls"]["max"] < 2e-2
     assert r["mse_rel_delta_ls"]["batch"] < 1e-3                    # and it does not bias the batch statistic
+
+
+def test_device_nearest_plan_divergence_from_ckdtree_is_measured_and_bounded():
+    """'nearest' (griddata(method='nearest') = cKDTree, src/baseline_estimators.py:65-79): SURVEY 7 counted 14.6 % of the resource
+    elements with two or more pilots at exactly the minimum distance.  The device search (batch path) takes the smallest pilot ordinal,
+    cKDTree whatever its traversal meets first.  Same frames through both plans (missing 5): both always pick A nearest
+    pilot, they differ at tied elements only, and the divergence is a recorded number.  The drop-in LSEstimator('nearest') uses the
+    cKDTree plan itself and has no such term."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import plan_parity
+    r = plan_parity.measure_nearest(P=838, patterns=16)
+    print(r)
+    assert 0.08 < r["tie_frac"] < 0.25                               # SURVEY: 14.6 %
+    assert r["picks_differing_at_untied_elements"] == 0
+    assert 0.0 < r["pick_differs"] <= r["tie_frac"]
+    assert r["H_ls"]["re_frac_gt_1e5"] <= r["pick_differs"] * 1.0001 and r["H_ls"]["rel_l2"] < 0.5
+    assert r["mse_rel_delta_ls"]["batch"] < 2e-2

@@ -97,7 +97,7 @@ def mfma_busy(src, dst, R):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--round", default="r04")
+    ap.add_argument("--round", default="r05")
     ap.add_argument("--only-mfma", action="store_true")
     a = ap.parse_args()
     R = a.round
@@ -108,7 +108,7 @@ def main():
              "footprint_sweep.txt", "bench_cfg4_pf_125000.json", "bench_cfg4_pf_10000.json", "bench_cfg4_shared_125000.json", "bench_cfg5_12500.json",
              "bench_cfg5_chunks1.json", "bench_cfg5_chunks2.json", "bench_cfg5_chunks4.json", "bench_cfg5_chunks8.json",
              "bench_cfg1.json", "bench_cfg2.json", "bench_cfg3.json", "bench_cfg4.json", "bench_cfg5.json", "bench_cfg2_pattern_per_frame.json",
-             "bench_cfg2_pattern_per_frame_resident.json", "bench_cfg4_pattern_per_frame.json", "bench_cfg2_gloo2_one_gpu.json",
+             "bench_cfg2_pattern_per_frame_resident.json", "bench_cfg4_pattern_per_frame.json", "bench_cfg2_gloo2_one_gpu.json", "bench_cfg5_gloo2_one_gpu.json",
              "ab_paths_cfg1.txt", "ab_paths_cfg2.txt", "ab_paths_cfg3.txt", "ablate_outputs.txt", "stamps_frame_kernel.txt",
              "stamps_pattern_kernel.txt", "bench_patterns.txt", "bench_prepare.txt", "dropin_latency.txt", "bench_cubic.txt",
              "pmc_sq_frame_kernel.txt"]

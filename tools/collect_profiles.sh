@@ -1,9 +1,9 @@
 #!/bin/bash
 # Collects the round's measured artefacts on the GPU box into gpurun_out/$ROUND/ (copied into profiles/ afterwards by tools/assemble_profiles.py).
-#   [ROUND=r04] bash tools/collect_profiles.sh [part]     part = bench | prof | mfma | tools | all
+#   [ROUND=r05] bash tools/collect_profiles.sh [part]     part = bench | prof | mfma | tools | all
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-ROUND=${ROUND:-r04}
+ROUND=${ROUND:-r05}
 O=$R/gpurun_out/$ROUND
 mkdir -p $O
 part=${1:-all}
@@ -17,7 +17,10 @@ if [ "$part" = bench ] || [ "$part" = all ]; then
   timeout -k 10 500 python bench.py --workload cfg4_dataset_mixed > $O/bench_cfg4.json 2>> $O/bench.err
   timeout -k 10 300 python bench.py --workload cfg4_dataset_mixed --pattern-group 1 --no-cpu-baseline > $O/bench_cfg4_pattern_per_frame.json 2>> $O/bench.err
   timeout -k 10 900 python bench.py --workload cfg5_4x4_2048_fullcov > $O/bench_cfg5.json 2>> $O/bench.err
-  timeout -k 10 300 python bench.py --rccl-rehearsal --no-cpu-baseline --no-extra-legs > $O/bench_cfg2_rccl_one_rank.json 2>> $O/bench.err
+  timeout -k 10 300 python bench.py --rccl-rehearsal --cpu-budget-s 5 --no-extra-legs > $O/bench_cfg2_rccl_one_rank.json 2>> $O/bench.err
+  # the N = 2 line end to end, two gloo ranks sharing the one GPU: collective_ms, per_rank and cpu_baseline at N > 1
+  timeout -k 10 300 python bench.py --gpus 2 --dist-backend gloo --cpu-budget-s 5 > $O/bench_cfg2_gloo2_one_gpu.json 2>> $O/bench.err
+  timeout -k 10 300 python bench.py --gpus 2 --dist-backend gloo --workload cfg5_4x4_2048_fullcov --no-cpu-baseline > $O/bench_cfg5_gloo2_one_gpu.json 2>> $O/bench.err
   echo bench done
 fi
 if [ "$part" = prof ] || [ "$part" = all ]; then
@@ -44,6 +47,10 @@ if [ "$part" = tools ] || [ "$part" = all ]; then
   timeout -k 10 200 python tools/bench_patterns.py > $O/bench_patterns.txt 2>&1
   bash tools/pmc_pattern_phases.sh 838 > $O/pmc_pattern_phases_P838.txt 2>&1
   bash tools/pmc_pattern_phases.sh 83 > $O/pmc_pattern_phases_P83.txt 2>&1
-  bash tools/r3_pmc_pat.sh > $O/pmc_sq_pattern_kernel.txt 2>&1
+  bash tools/pmc_pattern_sq.sh > $O/pmc_sq_pattern_kernel.txt 2>&1
+  (timeout -k 10 200 python tools/plan_parity.py --pilots 838 --patterns 64; timeout -k 10 200 python tools/plan_parity.py --pilots 419 --patterns 64;
+   timeout -k 10 300 python tools/plan_parity.py --pilots 838 --method nearest; timeout -k 10 300 python tools/plan_parity.py --pilots 419 --method nearest) > $O/plan_parity.txt 2>&1
+  timeout -k 10 200 python tools/bench_cubic.py > $O/bench_cubic.txt 2>&1
+  timeout -k 10 200 python tools/dropin_latency.py --frames 100 > $O/dropin_latency.txt 2>&1
   echo tools done
 fi

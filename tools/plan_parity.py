@@ -82,12 +82,72 @@ def measure(P=838, patterns=64, geometry=None, channel="EVA", doppler_hz=111.1, 
         ref.close()
 
 
+def measure_nearest(P=838, patterns=32, geometry=None, channel="EVA", doppler_hz=111.1, snr_db=10.0, seed=2024, first_id=0, device=0):
+    """The same question for 'nearest' (griddata(method='nearest') = cKDTree, src/baseline_estimators.py:65-79): on the integer lattice
+    many resource elements have TWO OR MORE pilots at exactly the smallest distance; cKDTree returns whichever its traversal meets
+    first, the device search the smallest pilot ordinal.  Same frames through both plans:
+
+      tie_frac          fraction of resource elements with more than one pilot at the minimum distance (exact integer arithmetic)
+      pick_differs      fraction of resource elements whose chosen pilot differs (only tied elements can: asserted)
+      H_ls / mse_*      as in `measure`"""
+    import torch
+    E = importlib.import_module(PKG + ".engine")
+    IP = importlib.import_module(PKG + ".interp_plan")
+    geom = geometry or E.Geometry()
+    S, nsc, G = geom.num_symbols, geom.num_sc, geom.grid
+    dev = E.Engine(geom, device)
+    ref = E.Engine(geom, device)
+    try:
+        ids = np.arange(first_id, first_id + patterns, dtype=np.uint64)
+        slots = dev.build_patterns(0, [P] * patterns, seed=seed, pattern_ids=ids, method="nearest")
+        dev.check_status()
+        gs, gk = np.divmod(np.arange(G), nsc)
+        ties, differs, differs_untied = [], [], 0
+        for j in range(patterns):
+            pil = dev.get_pilots(int(slots[j]))
+            ps, pk = np.unravel_index(pil.astype(np.int64), (S, nsc))
+            plan = IP.nearest_plan(ps, pk, S, nsc)                                  # cKDTree's picks
+            ref.set_pattern(j, pil, plan)
+            mine = dev.get_plan(int(slots[j]))[0][0].astype(np.int64)               # the device's picks (ordinal of weight 1)
+            theirs = np.asarray(plan[0][0], dtype=np.int64)
+            d2 = (gs[:, None] - ps[None, :]) ** 2 + (gk[:, None] - pk[None, :]) ** 2    # exact squared lattice distances [G, P]
+            dmin = d2.min(axis=1)
+            tied = (d2 == dmin[:, None]).sum(axis=1) > 1
+            assert np.array_equal(d2[np.arange(G), mine], dmin) and np.array_equal(d2[np.arange(G), theirs], dmin), "both must pick A nearest pilot"
+            ties.append(float(tied.mean()))
+            differs.append(float((mine != theirs).mean()))
+            differs_untied += int(((mine != theirs) & ~tied).sum())
+        names = ("H", "rx", "H_ls", "metrics")
+        d = E.make_descs(channel, doppler_hz, snr_db, np.arange(patterns, dtype=np.int32), n=patterns)
+        a = dev.run_frames(d, seed=seed, frame_offset=first_id, outputs=names)
+        b = ref.run_frames(d, seed=seed, frame_offset=first_id, outputs=names)
+        torch.cuda.synchronize()
+        assert torch.equal(a["H"], b["H"]) and torch.equal(a["rx"], b["rx"])
+        x, y = a["H_ls"].reshape(patterns, -1), b["H_ls"].reshape(patterns, -1)
+        diff = (x - y).abs()
+        scale = float(y.abs().max())
+        ma, mb = a["metrics"].double().cpu().numpy(), b["metrics"].double().cpu().numpy()
+        rel = np.abs(ma[:, 1] - mb[:, 1]) / mb[:, 1]
+        return {"pilots": int(P), "patterns": int(patterns), "method": "nearest", "tie_frac": float(np.mean(ties)),
+                "pick_differs": float(np.mean(differs)), "picks_differing_at_untied_elements": differs_untied,
+                "H_ls": {"re_frac_gt_1e5": float((diff > 1e-5 * scale).double().mean()), "max_over_scale": float(diff.max()) / scale,
+                         "rel_l2": float(torch.linalg.vector_norm(diff.double()) / torch.linalg.vector_norm(y.abs().double()))},
+                "mse_rel_delta_ls": {"mean": float(rel.mean()), "max": float(rel.max()),
+                                     "batch": float(abs(ma[:, 1].sum() - mb[:, 1].sum()) / mb[:, 1].sum())}}
+    finally:
+        dev.close()
+        ref.close()
+
+
 if __name__ == "__main__":
     import argparse
     import json
     ap = argparse.ArgumentParser()
     ap.add_argument("--pilots", type=int, default=838)
     ap.add_argument("--patterns", type=int, default=64)
-    ap.add_argument("--method", default="linear_compact")
+    ap.add_argument("--method", default="linear_compact", help="linear | linear_compact | nearest")
     a = ap.parse_args()
-    print(json.dumps(measure(a.pilots, a.patterns, method=a.method)))
+    if a.method == "nearest":
+        print(json.dumps(measure_nearest(a.pilots, min(a.patterns, 32))))
+    else:
+        print(json.dumps(measure(a.pilots, a.patterns, method=a.method)))
