@@ -90,10 +90,11 @@ struct chest_ctx {
     struct ProfSpan { int32_t id; void* a; void* b; };     // hipEvent_t pair around one kernel (group) of kind `id` (CHEST_K_*)
     std::vector<ProfSpan> prof_spans;     // pool created by chest_profile_begin; launches never allocate
     int32_t prof_used = 0;                // spans recorded since chest_profile_begin / the last chest_profile_read
-    size_t lds_opt_in[33] = {};   // largest dynamic-LDS size already opted in per kernel (per context = per device)
+    size_t lds_opt_in[40] = {};   // largest dynamic-LDS size already opted in per kernel (per context = per device)
     // chest_tune (tools / experiments only; nothing on the launch path reads the environment)
     int32_t tune_rx_group = 0;            // rx antennas per slab unit of the frame kernel (0 = chosen from the LDS budget)
     int32_t tune_taps_threads = 0;        // taps kernel workgroup size 64 / 128 / 256 (0 = by antenna count)
+    int32_t tune_interp_mode = 0;         // interp_from_pilots_tfold_kernel<MODE>: 2 / 3 diagnostic (no plan reads / no stores); 0 = the product
     int32_t tune_interp_xcd = 0;          // -1: interp_from_pilots_tfold_kernel without the XCD-contiguous row ranges (A/B)
     int32_t tune_gemm_f32 = 0;            // 1: the full-covariance filter on the exact-f32 MFMA kernel (cgemm_w_kernel_3m) instead of the fp16-split one (A/B)
     int32_t tune_two_slabs = 0;           // -1: no second slab for the one-workgroup-per-CU frame kernel (A/B)
@@ -120,7 +121,8 @@ void set_error(const char* fmt, ...);
 
 enum { LDS_TAPS = 0, LDS_FRAME = 1, LDS_ESTIMATE = 2, LDS_INTERP = 3, LDS_GEMM = 4, LDS_GEMM3M = 5, LDS_FRAME_640 = 6,
        LDS_FRAME_1024 = 7, LDS_FRAME_ROWS = 8, LDS_DELAUNAY = 9, LDS_FRAME_44 = 10, LDS_FRAME_11 = 11, LDS_FRAME_GEN = 12, LDS_FRAME_W5 = 13, LDS_GJ_PANEL = 14, LDS_GJ_UPDATE = 15, LDS_GJ_PANEL_R = 16, LDS_GJ_UPDATE_R = 17, LDS_FRAME_640_44 = 18, LDS_INTERP_TFOLD = 19,
-       LDS_FRAME_CP = 20, LDS_FRAME_44_CP = 21, LDS_FRAME_11_CP = 22, LDS_FRAME_GEN_CP = 23, LDS_DELAUNAY_CP = 24, LDS_DELAUNAY_NEAREST = 25, LDS_FRAME_640_44_MF = 26, LDS_FRAME_W6 = 27, LDS_FRAME_CP_W5 = 28, LDS_FRAME_11_CP_W5 = 29, LDS_FRAME_11_W5 = 30, LDS_FRAME_11_W7 = 31, LDS_FRAME_44_W5 = 32 };
+       LDS_FRAME_CP = 20, LDS_FRAME_44_CP = 21, LDS_FRAME_11_CP = 22, LDS_FRAME_GEN_CP = 23, LDS_DELAUNAY_CP = 24, LDS_DELAUNAY_NEAREST = 25, LDS_FRAME_640_44_MF = 26, LDS_FRAME_W6 = 27, LDS_FRAME_CP_W5 = 28, LDS_FRAME_11_CP_W5 = 29, LDS_FRAME_11_W5 = 30, LDS_FRAME_11_W7 = 31, LDS_FRAME_44_W5 = 32,
+       LDS_INTERP_TFOLD2 = 33, LDS_INTERP_TFOLD3 = 34 };
 
 // RAII: make the context's device current for the duration of an entry point and restore the caller's afterwards
 struct DeviceGuard {

@@ -434,6 +434,13 @@ interp_from_pilots_kernel(int S, int R, int T, int nsc, int Ppad, const PatternD
 // T * nsc elements -- leave as consecutive 128-B-line-aligned 1 KiB wave stores that read the LDS row modulo nsc.
 typedef float v4f_i __attribute__((ext_vector_type(4)));
 typedef float v2f_i __attribute__((ext_vector_type(2)));
+// MODE 0: the product.  MODE 2 / 3 (diagnostic, chest_tune "interp_mode"): no plan reads -- the pure store pattern -- / no stores -- the
+// gather alone.  Round 5 (profiles/r05_interp_modes.txt): 0.92 / 0.92 / 0.13 ms per 2 304 config-5 frames: the kernel IS its store stream,
+// and a pure-store model of one workgroup per 38-KB span runs at the same 5.2-5.6 TB/s (tools/micro/store_spans.hip) while a fill of the
+// same tensor in 4-KiB tiles runs at 6.9-7.0.  Built, bit-identical, measured and dropped (EXPERIMENTS.md, round 5): next symbol's plan
+// records prefetched (0.93), one workgroup per span in memory order (0.92), the page-class form -- every XCD writing only the 4-KiB
+// pages of one residue class mod 8, which is what makes the tile fill fast -- (1.10; 0.98 with its gather removed).
+template <int MODE>
 __global__ void __launch_bounds__(256)
 interp_from_pilots_tfold_kernel(int S, int R, int T, int nsc, int Ppad, const PatternDev* __restrict__ patterns, int slot,
                                 const float2* __restrict__ h, float2* __restrict__ H_est, int xcd_ranges) {
@@ -456,12 +463,16 @@ interp_from_pilots_tfold_kernel(int S, int R, int T, int nsc, int Ppad, const Pa
     const float inv_nsc = 1.0f / (float)nsc;
     for (int s = 0; s < S; ++s) {
         __syncthreads();                                            // hp ready / previous symbol's row fully read
-        for (int k = tid; k < nsc; k += blockDim.x) row[k] = interp(ld_plan(plan, s * nsc + k), hp, 1, 0);
+        if constexpr (MODE == 2) {
+            for (int k = tid; k < nsc; k += blockDim.x) row[k] = hp[k + s < P ? k + s : 0];
+        } else {
+            for (int k = tid; k < nsc; k += blockDim.x) row[k] = interp(ld_plan(plan, s * nsc + k), hp, 1, 0);
+        }
         __syncthreads();
         float2* __restrict__ g0 = H_est + ((size_t)(b * S + s) * R + r) * T * nsc;
         const int head = (int)(((uintptr_t)g0 & 127u) >> 3);
         const int nst = (head + n + 127) >> 7;
-        for (int q = wave; q < nst; q += 4) {
+        for (int q = wave; q < (MODE == 3 ? (s == 0 ? 1 : 0) : nst); q += 4) {
             const int e = (q << 7) - head + 2 * lane;
             if (e >= -1 && e < n) {
                 const int ec = e < 0 ? 0 : e;
@@ -810,10 +821,18 @@ int chest_mmse_full_interp_pilots(chest_ctx* ctx, void* stream, int32_t B, int32
     const int P = pd.P, Ppad = pad16(P), M = B * f.R;
     const float2* h_out = (const float2*)h_scratch + (size_t)pad128(M) * Ppad;
     const size_t lds = ((size_t)((P + 1) & ~1) + (size_t)f.nsc) * sizeof(float2);
-    CHEST_LDS_OPT_IN(ctx, LDS_INTERP_TFOLD, interp_from_pilots_tfold_kernel, lds);
+    const int mode = ctx->tune_interp_mode;
     const int sp_int = prof_open(ctx, st, CHEST_K_INTERP);
-    hipLaunchKernelGGL(interp_from_pilots_tfold_kernel, dim3(M), dim3(256), lds, st, f.S, f.R, f.T, f.nsc, Ppad, ctx->d_patterns,
-                       slot, h_out, (float2*)H_est, ctx->tune_interp_xcd >= 0 ? 1 : 0);
+#define CHEST_INTERP_LAUNCH(MODE, OPT)                                                                                             \
+    {                                                                                                                              \
+        CHEST_LDS_OPT_IN(ctx, OPT, interp_from_pilots_tfold_kernel<MODE>, lds);                                                   \
+        hipLaunchKernelGGL(interp_from_pilots_tfold_kernel<MODE>, dim3(M), dim3(256), lds, st, f.S, f.R, f.T, f.nsc, Ppad,        \
+                           ctx->d_patterns, slot, h_out, (float2*)H_est, ctx->tune_interp_xcd >= 0 ? 1 : 0);                      \
+    }
+    if (mode == 2) CHEST_INTERP_LAUNCH(2, LDS_INTERP_TFOLD2)
+    else if (mode == 3) CHEST_INTERP_LAUNCH(3, LDS_INTERP_TFOLD3)
+    else CHEST_INTERP_LAUNCH(0, LDS_INTERP_TFOLD)
+#undef CHEST_INTERP_LAUNCH
     prof_close(ctx, st, sp_int);
     CHEST_HIP(hipGetLastError());
     return CHEST_OK;
