@@ -471,8 +471,9 @@ def measure_leg(job, args, workload, group, steps, warmup, frames=None, patterns
                    for snr in sweep]
         d_first = d_sweep[0]
 
-    # Output buffers are allocated once and reused by every step (--placement-tries > 1 probes several allocations with
-    # the real kernel and keeps the fastest, Engine.place_outputs; the default takes the first allocation).
+    # Output buffers are allocated once and reused by every step.  Which allocation they are matters (a stable 20 % between
+    # independently allocated sets, Engine.place_outputs): --placement-tries candidates per tensor group are probed with the real
+    # kernel here, before the timed region, and the fastest combination is kept; every level seen is in `config.output_placement`.
     out, placement = eng.place_outputs(d_first, names, seed=seed, tries=args.placement_tries)
     torch.cuda.synchronize()
 
@@ -956,9 +957,11 @@ def main():
                          "scipy.spatial.Delaunay, uploaded as simplices (default: the timed frames equal griddata's); device = the "
                          "device triangulator's.  A pattern per frame (--pattern-group 1) is always triangulated on the device")
     ap.add_argument("--plan-workers", type=int, default=0, help="host processes for plan building with --patterns host (0 = min(16, cores))")
-    ap.add_argument("--placement-tries", type=int, default=1,
-                    help="candidate allocations per output tensor group (1 = take the first allocation, the default; "
-                         ">1 probes placements with the real kernel and keeps the fastest)")
+    ap.add_argument("--placement-tries", type=int, default=3,
+                    help="candidate allocations per output tensor group, probed with the real kernel BEFORE the timed region (clocks "
+                         "settled first, two round-robin passes); the fastest combination is kept (Engine.place_outputs: the frame "
+                         "kernel's write level is a stable property of the allocation it writes into, profiles/r05_placement_levels.txt). "
+                         "1 = take the first allocation")
     ap.add_argument("--pipeline-chunks", type=int, default=1,
                     help="cfg5: chunks of the batch pipelined over three streams (frame kernel | MFMA filter | interpolation); 1 = in sequence")
     ap.add_argument("--single-snr", action="store_true", help="cfg3: one launch at SNR 10 dB per step instead of the eight-point sweep")

@@ -278,7 +278,7 @@ def test_place_outputs_returns_usable_buffers():
     names = ["tx", "rx", "H", "H_ls", "H_mmse", "pilot_symbols", "pilot_mask", "metrics"]
     out, rep = eng.place_outputs(descs, names, seed=5, tries=2)
     assert set(out) == set(names) and rep["combinations"] == 4
-    assert rep["kernel_ms_best"] <= rep["kernel_ms_median"] <= rep["kernel_ms_worst"]
+    assert rep["step_ms_best"] <= rep["step_ms_median"] <= rep["step_ms_worst"]
     eng.run_frames(descs, seed=5, frame_offset=7, outputs=names, out=out)
     ref = eng.run_frames(descs, seed=5, frame_offset=7, outputs=names)
     for n in names:
