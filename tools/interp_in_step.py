@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""Config 5's interpolation kernel takes 0.91 ms when launched alone and 1.01 ms inside the step (after the frame kernel and the filter
+GEMM).  Which predecessor costs it the 10 %?  Sequences of the step's kernels, per-kernel times from the library's HIP events.
+    python tools/interp_in_step.py [frames=2304]"""
+import importlib, os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+E = importlib.import_module("channel-estimation-in-5g-network_amd.engine")
+F = int(sys.argv[1]) if len(sys.argv) > 1 else 2304
+geom = E.Geometry(fft_size=2048, cp_length=144, useful_subcarriers=1200, num_tx=4, num_rx=4)
+eng = E.Engine(geom, 0)
+S, nsc, G, R, T = geom.num_symbols, geom.num_sc, geom.grid, 4, 4
+P = int(G * 0.1)
+slot = int(eng.build_patterns(0, [P], seed=1, pattern_ids=np.asarray([0], np.uint64), method="linear")[0])
+descs = E.make_descs("ETU", 555.6, 10.0, np.full(F, slot, np.int32), n=F)
+d_dev = torch.from_numpy(descs.view(np.uint8).copy()).to(eng.device)
+names = ["tx", "rx", "H", "pilot_symbols", "pilot_mask", "h_ls_pilots"]
+out = eng.run_frames(d_dev, seed=1, outputs=names)
+W = eng.empty_c64(P, P)
+torch.view_as_real(W).normal_(); W *= 1.0 / P
+Wp = eng.mmse_full_pack_filter(W)
+scr = eng.mmse_full_scratch(slot, F * R)
+hm = eng.empty_c64(F, S, R, T, nsc)
+frame = lambda: eng.run_frames(d_dev, seed=1, outputs=names, out=out, check=False)
+gemm = lambda: eng.mmse_full_filter_pilots(out["h_ls_pilots"], slot, Wp, scr, pads_are_zero=True)
+interp = lambda: eng.mmse_full_interp_pilots(F, slot, scr, hm)
+idle = lambda: torch.cuda._sleep(2_000_000)            # ~1 ms of a spinning kernel: the chip busy with nothing
+frame(); gemm(); interp(); torch.cuda.synchronize()
+for label, seq in (("interp alone", [interp]), ("gemm, interp", [gemm, interp]), ("frame, interp", [frame, interp]),
+                   ("frame, gemm, interp (the step)", [frame, gemm, interp]), ("frame, gemm, sleep 1 ms, interp", [frame, gemm, idle, interp]),
+                   ("interp, interp", [interp, interp]), ("interp alone", [interp])):
+    for _ in range(5):
+        for f in seq:
+            f()
+    torch.cuda.synchronize()
+    eng.profile_begin(40 * len(seq) * 2)
+    for _ in range(10):
+        for f in seq:
+            f()
+    torch.cuda.synchronize()
+    k = eng.profile_read_all()
+    eng.profile_begin(0)
+    print(f"{label:34s} " + "  ".join(f"{n} {v:.3f}" for n, v in k.items()), flush=True)
