@@ -501,6 +501,7 @@ int chest_tune(chest_ctx* ctx, const char* key, int32_t value) {
     if (strcmp(key, "frame_two_slabs") == 0) { ctx->tune_two_slabs = value < 0 ? -1 : 0; return CHEST_OK; }
     if (strcmp(key, "gemm_f32") == 0) { ctx->tune_gemm_f32 = value ? 1 : 0; return CHEST_OK; }
     if (strcmp(key, "interp_mode") == 0) { ctx->tune_interp_mode = (value == 2 || value == 3) ? value : 0; return CHEST_OK; }
+    if (strcmp(key, "interp_touch") == 0) { ctx->tune_interp_touch = value; return CHEST_OK; }
     if (strcmp(key, "interp_xcd") == 0) { ctx->tune_interp_xcd = value < 0 ? -1 : 0; return CHEST_OK; }
     if (strcmp(key, "frame_store_extra") == 0) { ctx->tune_store_extra = (value >= -1 && value <= 4) ? value : 0; return CHEST_OK; }
     if (strcmp(key, "frame_store_waves") == 0) { ctx->tune_store_waves = (value >= 0 && value <= 16) ? value : 0; return CHEST_OK; }

@@ -95,6 +95,7 @@ struct chest_ctx {
     int32_t tune_rx_group = 0;            // rx antennas per slab unit of the frame kernel (0 = chosen from the LDS budget)
     int32_t tune_taps_threads = 0;        // taps kernel workgroup size 64 / 128 / 256 (0 = by antenna count)
     int32_t tune_interp_mode = 0;         // interp_from_pilots_tfold_kernel<MODE>: 2 / 3 diagnostic (no plan reads / no stores); 0 = the product
+    int32_t tune_interp_touch = 0;        // interp_from_pilots_tfold_kernel: rows ahead whose pilot values a workgroup touches (0 = one CU-slot generation, -1 = off)
     int32_t tune_interp_xcd = 0;          // -1: interp_from_pilots_tfold_kernel without the XCD-contiguous row ranges (A/B)
     int32_t tune_gemm_f32 = 0;            // 1: the full-covariance filter on the exact-f32 MFMA kernel (cgemm_w_kernel_3m) instead of the fp16-split one (A/B)
     int32_t tune_two_slabs = 0;           // -1: no second slab for the one-workgroup-per-CU frame kernel (A/B)

@@ -443,7 +443,7 @@ typedef float v2f_i __attribute__((ext_vector_type(2)));
 template <int MODE>
 __global__ void __launch_bounds__(256)
 interp_from_pilots_tfold_kernel(int S, int R, int T, int nsc, int Ppad, const PatternDev* __restrict__ patterns, int slot,
-                                const float2* __restrict__ h, float2* __restrict__ H_est, int xcd_ranges) {
+                                const float2* __restrict__ h, float2* __restrict__ H_est, int xcd_ranges, int touch_ahead) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const PatternDev pat = patterns[slot];
     const int P = pat.P, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -458,6 +458,16 @@ interp_from_pilots_tfold_kernel(int S, int R, int T, int nsc, int Ppad, const Pa
     float2* row = hp + ((P + 1) & ~1);                              // [nsc]
     const int r = m % R, b = m / R;
     for (int i = tid; i < P; i += blockDim.x) hp[i] = h[(size_t)m * Ppad + i];
+    // Touch the pilot values of the row whose workgroup will take this workgroup's place: one dword per 128-B line, landing in
+    // this XCD's L2 while this row is interpolated.  Inside the step these values come from HBM (the filter GEMM has just written
+    // them) and a cold read inside a saturated write stream waits microseconds -- at the START of a workgroup, with its LDS and
+    // wave slots already held.  `touch_ahead` = rows between a workgroup and its successor on the same XCD (0: off).
+    uint32_t touched = 0;
+    if (touch_ahead > 0 && m + touch_ahead < (int)gridDim.x) {
+        const uint32_t* __restrict__ nx = (const uint32_t*)(h + (size_t)(m + touch_ahead) * Ppad);
+        const int nlines = (P * 8 + 127) >> 7;
+        if (tid < nlines) touched = nx[tid * 32];
+    }
     const gptr_plan plan = (gptr_plan)pat.plan;
     const int n = T * nsc;
     const float inv_nsc = 1.0f / (float)nsc;
@@ -492,6 +502,7 @@ interp_from_pilots_tfold_kernel(int S, int R, int T, int nsc, int Ppad, const Pa
             }
         }
     }
+    asm volatile("" :: "v"(touched));                               // the touch has landed (nothing uses its value)
 }
 
 // h_ls_pilots [M][stride] (as chest_frames_run writes it) -> GEMM A operand [Mpad][Ppad], zero padded
@@ -822,12 +833,16 @@ int chest_mmse_full_interp_pilots(chest_ctx* ctx, void* stream, int32_t B, int32
     const float2* h_out = (const float2*)h_scratch + (size_t)pad128(M) * Ppad;
     const size_t lds = ((size_t)((P + 1) & ~1) + (size_t)f.nsc) * sizeof(float2);
     const int mode = ctx->tune_interp_mode;
+    // rows between a workgroup and the one that follows it in the same CU slot: workgroups per CU (by LDS, at most 8 by waves) x 32 CUs
+    // of an XCD, in the XCD's contiguous row range (chest_tune "interp_touch": -1 = off, > 0 = that many rows)
+    const int per_cu = (int)std::min<size_t>(8, (160 * 1024) / ((lds + 1279) / 1280 * 1280));
+    const int touch_ahead = ctx->tune_interp_touch < 0 ? 0 : (ctx->tune_interp_touch > 0 ? ctx->tune_interp_touch : (ctx->tune_interp_xcd >= 0 ? per_cu * 32 : 0));
     const int sp_int = prof_open(ctx, st, CHEST_K_INTERP);
 #define CHEST_INTERP_LAUNCH(MODE, OPT)                                                                                             \
     {                                                                                                                              \
         CHEST_LDS_OPT_IN(ctx, OPT, interp_from_pilots_tfold_kernel<MODE>, lds);                                                   \
         hipLaunchKernelGGL(interp_from_pilots_tfold_kernel<MODE>, dim3(M), dim3(256), lds, st, f.S, f.R, f.T, f.nsc, Ppad,        \
-                           ctx->d_patterns, slot, h_out, (float2*)H_est, ctx->tune_interp_xcd >= 0 ? 1 : 0);                      \
+                           ctx->d_patterns, slot, h_out, (float2*)H_est, ctx->tune_interp_xcd >= 0 ? 1 : 0, touch_ahead);         \
     }
     if (mode == 2) CHEST_INTERP_LAUNCH(2, LDS_INTERP_TFOLD2)
     else if (mode == 3) CHEST_INTERP_LAUNCH(3, LDS_INTERP_TFOLD3)

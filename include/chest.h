@@ -226,7 +226,12 @@ int chest_profile_read_kernel(chest_ctx* ctx, int32_t kernel_id, float* ms, int3
  *   "pattern_solo_at"   workgroup-wide active triangles at which one wave takes over the Delaunay flips (0 = default)
  *   "pattern_stop_after" diagnostic: chest_patterns_build's kernel leaves after phase k = 1..5 (tools/pmc_pattern_phases.sh)
  *   "pattern_flip_cap"  flip rounds allowed per stage of chest_patterns_build (0 = the default, 4 * triangles + 64; a low
- *                       value forces the status-3 path for tests) */
+ *                       value forces the status-3 path for tests)
+ *   "frame_store_waves" / "frame_store_extra" / "frame_two_slabs" / "gemm_f32"   store-out crew, dedicated store waves, second slab of the
+ *                       frame kernel; 1 = the exact-f32 MFMA filter GEMM instead of the fp16-split one (A/B)
+ *   "interp_xcd" / "interp_touch" / "interp_mode"   chest_mmse_full_interp_pilots: -1 = rows in launch order instead of XCD-contiguous;
+ *                       rows ahead whose pilot values a workgroup touches (0 = default, -1 = off); 2 / 3 = diagnostic kernels without
+ *                       plan reads / without stores */
 int chest_tune(chest_ctx* ctx, const char* key, int32_t value);
 
 /* ---- launch group (asynchronous, no allocation) -------------------------------------------- */

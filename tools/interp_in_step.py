@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Config 5's interpolation kernel takes 0.91 ms when launched alone and 1.01 ms inside the step (after the frame kernel and the filter
 GEMM).  Which predecessor costs it the 10 %?  Sequences of the step's kernels, per-kernel times from the library's HIP events.
-    python tools/interp_in_step.py [frames=2304]"""
+    python tools/interp_in_step.py [frames=2304] [interp_touch values, e.g. -1,0,96]"""
 import importlib, os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -28,18 +28,22 @@ gemm = lambda: eng.mmse_full_filter_pilots(out["h_ls_pilots"], slot, Wp, scr, pa
 interp = lambda: eng.mmse_full_interp_pilots(F, slot, scr, hm)
 idle = lambda: torch.cuda._sleep(2_000_000)            # ~1 ms of a spinning kernel: the chip busy with nothing
 frame(); gemm(); interp(); torch.cuda.synchronize()
-for label, seq in (("interp alone", [interp]), ("gemm, interp", [gemm, interp]), ("frame, interp", [frame, interp]),
-                   ("frame, gemm, interp (the step)", [frame, gemm, interp]), ("frame, gemm, sleep 1 ms, interp", [frame, gemm, idle, interp]),
-                   ("interp, interp", [interp, interp]), ("interp alone", [interp])):
-    for _ in range(5):
-        for f in seq:
-            f()
-    torch.cuda.synchronize()
-    eng.profile_begin(40 * len(seq) * 2)
-    for _ in range(10):
-        for f in seq:
-            f()
-    torch.cuda.synchronize()
-    k = eng.profile_read_all()
-    eng.profile_begin(0)
-    print(f"{label:34s} " + "  ".join(f"{n} {v:.3f}" for n, v in k.items()), flush=True)
+touches = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [0]
+for touch in touches:
+  eng.tune("interp_touch", touch)
+  print(f"-- chest_tune interp_touch {touch}  (-1 = off, 0 = default distance, n = rows ahead)")
+  for label, seq in (("interp alone", [interp]), ("gemm, interp", [gemm, interp]), ("frame, interp", [frame, interp]),
+                     ("frame, gemm, interp (the step)", [frame, gemm, interp]), ("frame, gemm, sleep 1 ms, interp", [frame, gemm, idle, interp]),
+                     ("interp, interp", [interp, interp]), ("interp alone", [interp])):
+      for _ in range(5):
+          for f in seq:
+              f()
+      torch.cuda.synchronize()
+      eng.profile_begin(40 * len(seq) * 2)
+      for _ in range(10):
+          for f in seq:
+              f()
+      torch.cuda.synchronize()
+      k = eng.profile_read_all()
+      eng.profile_begin(0)
+      print(f"{label:34s} " + "  ".join(f"{n} {v:.3f}" for n, v in k.items()), flush=True)
