@@ -475,3 +475,30 @@ def test_matrix_pipe_tap_sums_of_the_2048_fft_4x4_launch(ctype):
         assert relerr(out["rx"][b].cpu().numpy(), o["rx_symbols"]) < TOL
         assert relerr(out["tx"][b].cpu().numpy(), o["tx_symbols"]) < TOL
     eng.close()
+
+
+def test_interpolation_kernel_variants_write_the_same_bits():
+    """chest_mmse_full_interp_pilots: the touch of the successor row's pilot values (round 5; chest_tune "interp_touch") and the
+    XCD-contiguous row order ("interp_xcd") only change WHEN bytes move -- every setting writes the same H_mmse, also for a batch whose
+    row count is not a multiple of the touch distance and for the last rows (whose successor does not exist)."""
+    geom = E.Geometry(fft_size=1024, cp_length=72, num_symbols=14, useful_subcarriers=300, num_tx=4, num_rx=4)
+    eng = E.Engine(geom, 0)
+    rs = np.random.RandomState(5)
+    P = 400
+    slot = eng.pattern_slot(np.sort(rs.permutation(geom.grid)[:P]), "linear")
+    B = 301                                                               # 1 204 rows: several generations of 192, ragged end
+    scr = eng.mmse_full_scratch(slot, B * 4)
+    scr.view(torch.float32).normal_()
+    want = None
+    for touch, xcd in ((0, 0), (-1, 0), (7, 0), (5000, 0), (0, -1), (-1, -1)):
+        eng.tune("interp_touch", touch); eng.tune("interp_xcd", xcd)
+        out = eng.empty_c64(B, geom.num_symbols, 4, 4, geom.num_sc)
+        out.fill_(complex(float("nan"), 0.0))
+        eng.mmse_full_interp_pilots(B, slot, scr, out)
+        torch.cuda.synchronize()
+        assert torch.isfinite(torch.view_as_real(out)).all(), (touch, xcd)
+        if want is None:
+            want = out
+        else:
+            assert torch.equal(torch.view_as_real(out), torch.view_as_real(want)), (touch, xcd)
+    eng.close()
